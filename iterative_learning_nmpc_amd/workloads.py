@@ -1,0 +1,126 @@
+"""Seeded synthetic inputs for the BASELINE.json configurations.
+
+No files, no network: everything is drawn from numpy `default_rng(seed)`.
+  config 1  double integrator  nx=4  nu=2  N=20  B=1     (plumbing)
+  config 2  centroidal quadruped nx=12 nu=12 N=50 B=1024 (headline)
+Weights are the reference's Go2 trot cost (mpc_controller/config/quadruped/mpc_cost.py:26-57),
+contact flags come from the trot gait table (contact_planner.py:121-134) at a random phase,
+base references from the velocity-tracking reference generator (mpc.py:210-272).
+Mass / inertia / hip offsets are declared Go2-like constants (not in the reference).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict
+
+import numpy as np
+
+from .config import get_quadruped_config
+from .contact_planner import ContactPlanner
+from .references import base_ref_vel_tracking
+
+FEET = ("FL_foot", "FR_foot", "RL_foot", "RR_foot")
+HIP_OFFSETS = np.array([[0.19, 0.14, 0.0], [0.19, -0.14, 0.0], [-0.19, 0.14, 0.0], [-0.19, -0.14, 0.0]])
+
+MODEL_DOUBLE_INTEGRATOR = 0
+MODEL_CENTROIDAL = 1
+MODEL_DIMS = {MODEL_DOUBLE_INTEGRATOR: dict(nx=4, nu=2, np=0, ng=4),
+              MODEL_CENTROIDAL: dict(nx=12, nu=12, np=16, ng=16)}
+
+# model parameter vector (shared layout with include/nmpc.h: NMPC_MP_*)
+MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax")
+
+
+def model_params(**kw) -> np.ndarray:
+    d = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0)
+    d.update(kw)
+    return np.array([d[k] for k in MP_NAMES], dtype=np.float64)
+
+
+@dataclass
+class Workload:
+    """One batch of independent NMPC problems (all arrays float64, batch-major)."""
+    model_id: int
+    N: int
+    mp: np.ndarray            # [8]
+    W: np.ndarray             # [nx+nu]
+    W_e: np.ndarray           # [nx]
+    x0: np.ndarray            # [B, nx]
+    yref: np.ndarray          # [B, N, nx+nu] per stage, or [B, nx+nu] stage-constant (solver.py:169)
+    yref_e: np.ndarray        # [B, nx]
+    params: np.ndarray        # [B, N+1, np]
+    X: np.ndarray             # [B, N+1, nx] warm start
+    U: np.ndarray             # [B, N, nu]   warm start
+    meta: Dict = field(default_factory=dict)
+
+    @property
+    def B(self) -> int:
+        return self.x0.shape[0]
+
+
+def double_integrator(B: int = 1, N: int = 20, seed: int = 0, umax: float = 0.0) -> Workload:
+    """Config 1: x=[p(2),v(2)], u=a(2), dt=0.05, W=diag(10,10,1,1,.1,.1), W_e = 10 Q."""
+    rng = np.random.default_rng(seed)
+    x0 = rng.uniform(-1, 1, (B, 4))
+    W = np.array([10.0, 10.0, 1.0, 1.0, 0.1, 0.1])
+    X = np.repeat(x0[:, None, :], N + 1, axis=1)
+    return Workload(MODEL_DOUBLE_INTEGRATOR, N, model_params(dt=0.05, umax=umax), W, 10.0 * W[:4], x0,
+                    np.zeros((B, N, 6)), np.zeros((B, 4)), np.zeros((B, N + 1, 0)), X,
+                    np.zeros((B, N, 2)), dict(config="1: double integrator"))
+
+
+def centroidal_trot(B: int = 1024, N: int = 50, seed: int = 0, warm: str = "stand") -> Workload:
+    """Config 2: centroidal quadruped, trot, T=1.0 s.
+
+    warm = "stand": X held at x0, every stance foot carries an equal share of the weight
+    (a feasible interior start); warm = "zero": U = 0 (first-solve case, solver.py:320 tail).
+    """
+    rng = np.random.default_rng(seed)
+    gait, opt, cost = get_quadruped_config("trot", "go2")
+    T = opt.time_horizon
+    dt = T / N
+    mp = model_params(dt=dt)
+    planner = ContactPlanner(FEET, dt, gait)
+
+    x0 = np.zeros((B, 12))
+    x0[:, 0:2] = rng.normal(0, 0.05, (B, 2))
+    x0[:, 2] = 0.30 + rng.normal(0, 0.02, B)
+    x0[:, 3:6] = rng.normal(0, 0.1, (B, 3))
+    x0[:, 6:9] = rng.normal(0, 0.2, (B, 3))
+    x0[:, 9:12] = rng.normal(0, 0.3, (B, 3))
+    v_des = np.stack([rng.uniform(0, 0.3, B), rng.uniform(-0.1, 0.1, B), np.zeros(B)], axis=1)
+    i_node = rng.integers(0, planner.nodes_per_cycle, B)
+
+    contacts = planner.get_contacts_batch(i_node, N + 1).astype(np.float64)   # [B,4,N+1]
+    feet = x0[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None] + rng.normal(0, 0.02, (B, 4, 3))
+    feet[:, :, 2] = 0.0
+    params = np.zeros((B, N + 1, 16))
+    params[:, :, :4] = np.moveaxis(contacts, 1, 2)
+    params[:, :, 4:] = feet.reshape(B, 1, 12)
+
+    # Per-stage output reference: the base part is stage-constant as in the reference
+    # (solver.py:169); the force part is the gravity-compensating share of each stance foot
+    # [decl]: without the reference's whole-body kinematic cost nothing else holds the base up.
+    n_stance = np.maximum(contacts[:, :, :N].sum(1), 1.0)                      # [B,N]
+    fz_share = np.moveaxis(contacts[:, :, :N], 1, 2) * ((-mp[5] * mp[1]) / n_stance)[:, :, None]
+    yref = np.zeros((B, N, 24))
+    yref[:, :, 14::3] = fz_share
+    yref_e = np.zeros((B, 12))
+    base = np.zeros((B, 12))
+    for b in range(B):
+        q = np.zeros(18)
+        q[:6] = x0[b, :6]
+        ref_state = np.zeros(12)
+        ref_state[:2] = x0[b, :2]
+        ref_state[3] = x0[b, 3]
+        base[b], yref_e[b] = base_ref_vel_tracking(q, v_des[b], np.zeros(3), ref_state, T,
+                                                   gait.nom_height)
+    yref[:, :, :12] = base[:, None, :]
+    W = np.concatenate([cost.W_base, cost.W_cnt_f_reg.ravel()])
+    X = np.repeat(x0[:, None, :], N + 1, axis=1)
+    U = np.zeros((B, N, 12))
+    if warm == "stand":
+        U[:, :, 2::3] = fz_share
+    return Workload(MODEL_CENTROIDAL, N, mp, W, cost.W_e_base.copy(), x0, yref, yref_e, params, X, U,
+                    dict(config="2: centroidal trot", v_des=v_des, i_node=i_node,
+                         reg=cost.reg_eps, reg_e=cost.reg_eps_e))
