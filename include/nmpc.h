@@ -1,0 +1,136 @@
+/*
+ * nmpc.h -- C-ABI of the MI355X (gfx950) batched NMPC solve path.
+ *
+ * This is the drop-in boundary for the hot path of Atarilab/iterative_learning_NMPC:
+ * what the reference reaches through
+ *     QuadrupedAcadosSolver.init / .solve            mpc_controller/utils/solver.py:355-429
+ *       -> AcadosSolverHelper.solve [contact_tamp, un-vendored] -> acados C-ABI
+ *          (<name>_acados_create / _solve / _free, ocp_nlp_*_set / _get; int status)
+ * is replaced by the entry points below.  Conventions:
+ *   - plain C types only; every pointer marked `dev` is a HIP device pointer (e.g. a torch
+ *     tensor's data_ptr()); `host` pointers are ordinary host memory; the caller owns all buffers;
+ *   - the library allocates its workspace in nmpc_create() only; no allocation, no
+ *     synchronisation in any *_batch call (they are stream-ordered and graph-capturable);
+ *   - every function returns 0 on success, a negative NMPC_E_* code on failure;
+ *     nmpc_last_error() gives the text.  Per-problem solver status goes to `status[B]`
+ *     with acados' codes (0 ok, 1 NaN, 2 max-iter, 3 min-step, 4 QP failure), replacing
+ *     the exception -> `diverged` convention of mpc_controller/mpc.py:562-569;
+ *   - thread-safety: a handle is not re-entrant (one solve in flight per handle, as the
+ *     reference's single worker thread, mpc.py:164,516); distinct handles are independent.
+ *     ctypes releases the GIL during calls, so a worker thread may drive a handle.
+ *   - layouts are batch-major, stage-major, feature-minor, fp32:
+ *        x0[B][nx]  yref[B][N][ny] | [B][ny]  yref_e[B][nx]  params[B][N+1][np]
+ *        X[B][N+1][nx]  U[B][N][nu]  status[B]  stats[B][4]
+ *     (the reference keeps [dim][node] numpy views, solver.py:88-92,169; the Python host
+ *      mirror transposes at its boundary).
+ */
+#ifndef NMPC_H
+#define NMPC_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- models (mathematics in DESIGN.md section 3) ---- */
+#define NMPC_MODEL_DOUBLE_INTEGRATOR 0 /* nx 4  nu 2  np 0  ng 4  (BASELINE config 1) */
+#define NMPC_MODEL_CENTROIDAL        1 /* nx 12 nu 12 np 16 ng 16 (BASELINE config 2) */
+
+/* model parameter vector, nmpc_set_model_params(): */
+#define NMPC_MP_DT    0 /* node spacing T/N                                  */
+#define NMPC_MP_MASS  1
+#define NMPC_MP_IXX   2
+#define NMPC_MP_IYY   3
+#define NMPC_MP_IZZ   4
+#define NMPC_MP_GZ    5 /* gravity along z (negative)                        */
+#define NMPC_MP_MU    6 /* friction coefficient (0.8, solver.py:38)          */
+#define NMPC_MP_UMAX  7 /* double integrator input box, <= 0 disables        */
+#define NMPC_MP_COUNT 8
+
+/* status codes written to status[B] (acados numbering) */
+#define NMPC_STATUS_OK       0
+#define NMPC_STATUS_NAN      1
+#define NMPC_STATUS_MAXITER  2
+#define NMPC_STATUS_MINSTEP  3
+#define NMPC_STATUS_QP       4
+
+/* return codes */
+#define NMPC_OK            0
+#define NMPC_E_ARG        -1 /* bad argument / dimension                      */
+#define NMPC_E_HIP        -2 /* HIP runtime error                             */
+#define NMPC_E_STATE      -3 /* weights / model parameters not set            */
+
+typedef struct {
+    int model_id;  /* NMPC_MODEL_*                                             */
+    int N;         /* horizon (number of shooting intervals)                  */
+    int B_max;     /* largest batch a *_batch call will be given              */
+    int precision; /* 0 = fp32 (only value implemented)                       */
+} nmpc_dims;
+
+/* Dimensions of a model.  Any out pointer may be NULL. */
+int nmpc_model_dims(int model_id, int *nx, int *nu, int *np, int *ng);
+
+/* Replaces <name>_acados_create (+ AcadosSolverHelper.setup, solver.py:68-72). */
+int nmpc_create(const nmpc_dims *dims, int device_id, void **handle);
+void nmpc_destroy(void *handle);
+const char *nmpc_last_error(void *handle); /* handle may be NULL: last create error */
+size_t nmpc_workspace_bytes(void *handle);
+
+/* host float[NMPC_MP_COUNT] */
+int nmpc_set_model_params(void *handle, const float *mp, int count);
+
+/* Replaces set_cost_weight_constant / set_cost_weight_terminal (solver.py:140-141) and the
+ * reg_eps / reg_eps_e constructor arguments (solver.py:53-54).  host W[ny], W_e[nx]. */
+int nmpc_set_weights(void *handle, const float *W, const float *W_e, float reg, float reg_e);
+
+/* Replaces set_max_iter / set_nlp_tol / set_qp_tol (solver.py:75-79, mpc.py:464-473) and
+ * setup(max_qp_iter) (solver.py:71).  max_qp_iter = number of interior-point iterations per
+ * SQP iteration (0: inequalities ignored).  nlp_tol <= 0 disables the early exit on
+ * max|step| < nlp_tol.  qp_tol is stored for API symmetry; the IPM runs a fixed
+ * iteration count.  line_search: 0 full step, 1 backtracking on the l1 merit. */
+int nmpc_set_opts(void *handle, int max_sqp_iter, int max_qp_iter, float nlp_tol, float qp_tol,
+                  int line_search);
+
+/* Declared interior-point constants; defaults 10, 0.2, 1, 0.995, 0.1, 1e3. */
+int nmpc_set_ipm(void *handle, float mu0, float sigma, float s_min, float gamma, float tau_min,
+                 float merit_rho);
+
+/* Replaces QuadrupedAcadosSolver.warm_start_solver (solver.py:290-342): shift the previous
+ * primal solution left by `shift` nodes, zero-fill the exposed input tail.  X, U dev in/out. */
+int nmpc_shift_warm_start(void *handle, int B, int shift, float *X, float *U, void *stream);
+
+/* Replaces update_solver + solve + parse_sol (solver.py:345-353,396-403): B independent
+ * NMPC problems, one per wavefront.  yref_per_stage: 1 = yref[B][N][ny], 0 = yref[B][ny].
+ * X/U: in warm start, out solution.  status / stats may be NULL.
+ * stats[b] = {cost at the last linearisation, max|step|, step length, SQP iterations}. */
+int nmpc_solve_batch(void *handle, int B, const float *x0, const float *yref, int yref_per_stage,
+                     const float *yref_e, const float *params, float *X, float *U, int *status,
+                     float *stats, void *stream);
+
+/* One Riccati sweep on explicit stage data (the LQ core of the solve), dense row-major dev
+ * inputs Q[B][N+1][nx][nx] R[B][N][nu][nu] q[B][N+1][nx] r[B][N][nu] A[B][N][nx][nx]
+ * B_[B][N][nx][nu] d[B][N][nx] dx0[B][nx]; outputs dX[B][N+1][nx] dU[B][N][nu] status[B].
+ * nx <= 15, nu <= 16.  Uses the handle's workspace: Bsz <= B_max, N == dims.N. */
+int nmpc_riccati_batch(void *handle, int Bsz, int nx, int nu, const float *Q, const float *R,
+                       const float *q, const float *r, const float *A, const float *B_,
+                       const float *d, const float *dx0, float *dX, float *dU, int *status,
+                       void *stream);
+
+/* Tracking error of B rollouts against the nominal one
+ * (Behavior_Cloning/utils/data_collection_force_perturbation.py:138-156):
+ *   err[b][t] = || S[b][t][1:] - S_nom[t][1:] ||_2      (column 0, the gait phase, is skipped)
+ * and, if weight != NULL, the sampling weight of Behavior_Cloning/examples/test_train_policy.py:127-134:
+ *   weight[b][t] = err > threshold ? ood_weight : 1.
+ * Needs no handle (pass NULL) -- stateless. */
+int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, const float *S_nom,
+                        float *err, float *weight, float threshold, float ood_weight, void *stream);
+
+/* Test hook: copy one stage tile of problem b out of the workspace after a solve.
+ * which: 0 = A~ (16x16, column-major, [A d; 0 1]), 1 = B~, 2 = K~ = [K kff] of the last sweep.
+ * out_host: float[256].  Synchronises the device. */
+int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMPC_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of libnmpc_hip.so (include/nmpc.h).  No fallback: if the HIP library is missing
+or does not load, importing callers get a loud ImportError -- there is no CPU path in the product."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmpc_hip.so")
+
+NMPC_OK = 0
+STATUS_NAMES = {0: "ok", 1: "nan", 2: "max_iter", 3: "min_step", 4: "qp_failure"}
+
+# every symbol include/nmpc.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "nmpc_model_dims": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "nmpc_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "nmpc_destroy": (None, [c_void_p]),
+    "nmpc_last_error": (c_char_p, [c_void_p]),
+    "nmpc_workspace_bytes": (c_size_t, [c_void_p]),
+    "nmpc_set_model_params": (c_int, [c_void_p, POINTER(c_float), c_int]),
+    "nmpc_set_weights": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), c_float, c_float]),
+    "nmpc_set_opts": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_int]),
+    "nmpc_set_ipm": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_float, c_float]),
+    "nmpc_shift_warm_start": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nmpc_solve_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_riccati_batch": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 12),
+    "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_float, c_float, c_void_p]),
+    "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
+}
+
+
+class NmpcDims(ctypes.Structure):
+    _fields_ = [("model_id", c_int), ("N", c_int), ("B_max", c_int), ("precision", c_int)]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library once; raise ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or iterative_learning_nmpc_amd/csrc/build.sh). "
+            "This package has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise ImportError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class NmpcError(RuntimeError):
+    pass
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    if rc != NMPC_OK:
+        msg = load().nmpc_last_error(handle)
+        raise NmpcError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

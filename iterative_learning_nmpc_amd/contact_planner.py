@@ -145,8 +145,8 @@ class RaiberContactPlanner(ContactPlanner):
             ratio = self.config_gait.stance_ratio[foot]
             t_stance = self.config_gait.nominal_period * ratio
             hip = com_xy + (R_yaw @ self.offset_hip_b[foot])[:2] + v_cmd * t_touch * (1 + ratio)
-            centrifugal = np.cross(0.5 * np.sqrt(com_z / self.GRAVITY) * v_cmd,
-                                   [0.0, 0.0, self.w_yaw])
+            lever = 0.5 * np.sqrt(com_z / self.GRAVITY) * v_cmd
+            centrifugal = np.array([lever[1] * self.w_yaw, -lever[0] * self.w_yaw])  # (lever,0) x (0,0,w)
             target = np.zeros(3)
             target[:2] = hip + 0.1 * (v_cmd - self.v_w[:2]) + 0.5 * v_cmd * t_stance + centrifugal[:2]
             target[2] = self.foot_size

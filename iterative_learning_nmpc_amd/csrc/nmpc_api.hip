@@ -1,0 +1,272 @@
+// nmpc_api.hip -- host side of the C-ABI declared in include/nmpc.h (libnmpc_hip.so).
+// Single translation unit: kernels are included below.  Build: csrc/build.sh (hipcc, gfx950).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "nmpc_solve.hip"
+#include "nmpc_aux.hip.inc"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Handle {
+    nmpc_dims dims{};
+    int device = 0;
+    int nx = 0, nu = 0, np = 0, ng = 0;
+    float* ws = nullptr;
+    size_t ws_bytes = 0;
+    bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
+    bool mp_set = false, w_set = false;
+    nmpc::ModelParams mp{};
+    float W[32]{}, We[16]{};
+    float reg = 1e-6f, reg_e = 1e-5f;
+    int max_sqp = 1, n_ipm = 6, line_search = 0;
+    float nlp_tol = 0.0f, qp_tol = 1e-2f;
+    float mu0 = 10.0f, sigma = 0.2f, s_min = 1.0f, gamma = 0.995f, tau_min = 0.1f, rho = 1e3f;
+    std::string err;
+};
+
+int fail(Handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(h, NMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class M>
+int launch_solve(Handle* h, const nmpc::SolveArgs& a, hipStream_t st) {
+    const nmpc::Lds<M> L(a.N);
+    const size_t bytes = (size_t)L.total * sizeof(float);
+    if (bytes > 160 * 1024) return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
+    if (bytes > 64 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_solve_kernel<M>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<M>, dim3(a.B), dim3(64), bytes, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nmpc_model_dims(int model_id, int* nx, int* nu, int* np, int* ng) {
+    int d[4];
+    if (model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) {
+        d[0] = nmpc::DoubleIntegrator::NX; d[1] = nmpc::DoubleIntegrator::NU;
+        d[2] = nmpc::DoubleIntegrator::NP; d[3] = nmpc::DoubleIntegrator::NG;
+    } else if (model_id == NMPC_MODEL_CENTROIDAL) {
+        d[0] = nmpc::Centroidal::NX; d[1] = nmpc::Centroidal::NU;
+        d[2] = nmpc::Centroidal::NP; d[3] = nmpc::Centroidal::NG;
+    } else {
+        return NMPC_E_ARG;
+    }
+    if (nx) *nx = d[0];
+    if (nu) *nu = d[1];
+    if (np) *np = d[2];
+    if (ng) *ng = d[3];
+    return NMPC_OK;
+}
+
+int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
+    if (!dims || !handle) return fail(nullptr, NMPC_E_ARG, "null argument");
+    *handle = nullptr;
+    int nx, nu, np, ng;
+    if (nmpc_model_dims(dims->model_id, &nx, &nu, &np, &ng)) return fail(nullptr, NMPC_E_ARG, "unknown model_id");
+    if (dims->N < 1 || dims->B_max < 1) return fail(nullptr, NMPC_E_ARG, "N and B_max must be positive");
+    if (dims->precision != 0) return fail(nullptr, NMPC_E_ARG, "only precision 0 (fp32) is implemented");
+    Handle* h = new Handle();
+    h->dims = *dims;
+    h->device = device_id;
+    h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) {
+        h->ws_bytes = (size_t)dims->B_max * 3 * dims->N * nmpc::TILE * sizeof(float);
+        e = hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes);
+    }
+    if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
+    if (e != hipSuccess) {
+        g_create_error = std::string("nmpc_create: ") + hipGetErrorString(e);
+        if (h->ws) (void)hipFree(h->ws);
+        delete h;
+        return NMPC_E_HIP;
+    }
+    *handle = h;
+    return NMPC_OK;
+}
+
+void nmpc_destroy(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+}
+
+const char* nmpc_last_error(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+size_t nmpc_workspace_bytes(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    return h ? h->ws_bytes : 0;
+}
+
+int nmpc_set_model_params(void* handle, const float* mp, int count) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !mp) return fail(h, NMPC_E_ARG, "null argument");
+    if (count != NMPC_MP_COUNT) return fail(h, NMPC_E_ARG, "model parameter vector must have NMPC_MP_COUNT entries");
+    if (!(mp[NMPC_MP_DT] > 0.0f)) return fail(h, NMPC_E_ARG, "dt must be positive");
+    if (h->dims.model_id == NMPC_MODEL_CENTROIDAL &&
+        !(mp[NMPC_MP_MASS] > 0 && mp[NMPC_MP_IXX] > 0 && mp[NMPC_MP_IYY] > 0 && mp[NMPC_MP_IZZ] > 0))
+        return fail(h, NMPC_E_ARG, "mass and inertia must be positive");
+    h->mp = nmpc::ModelParams{mp[0], mp[1], mp[2], mp[3], mp[4], mp[5], mp[6], mp[7]};
+    h->mp_set = true;
+    return NMPC_OK;
+}
+
+int nmpc_set_weights(void* handle, const float* W, const float* W_e, float reg, float reg_e) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !W || !W_e) return fail(h, NMPC_E_ARG, "null argument");
+    for (int i = 0; i < h->nx + h->nu; ++i) {
+        if (!(W[i] >= 0.0f)) return fail(h, NMPC_E_ARG, "weights must be non-negative");
+        h->W[i] = W[i];
+    }
+    for (int i = 0; i < h->nx; ++i) {
+        if (!(W_e[i] >= 0.0f)) return fail(h, NMPC_E_ARG, "weights must be non-negative");
+        h->We[i] = W_e[i];
+    }
+    if (!(reg >= 0.0f) || !(reg_e >= 0.0f)) return fail(h, NMPC_E_ARG, "regularisation must be non-negative");
+    h->reg = reg; h->reg_e = reg_e;
+    h->w_set = true;
+    return NMPC_OK;
+}
+
+int nmpc_set_opts(void* handle, int max_sqp_iter, int max_qp_iter, float nlp_tol, float qp_tol,
+                  int line_search) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (max_sqp_iter < 1 || max_qp_iter < 0) return fail(h, NMPC_E_ARG, "iteration counts out of range");
+    h->max_sqp = max_sqp_iter; h->n_ipm = max_qp_iter;
+    h->nlp_tol = nlp_tol; h->qp_tol = qp_tol; h->line_search = line_search ? 1 : 0;
+    return NMPC_OK;
+}
+
+int nmpc_set_ipm(void* handle, float mu0, float sigma, float s_min, float gamma, float tau_min,
+                 float merit_rho) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (!(mu0 > 0 && sigma > 0 && sigma < 1 && s_min > 0 && gamma > 0 && gamma < 1 && tau_min >= 0 && merit_rho >= 0))
+        return fail(h, NMPC_E_ARG, "interior-point constants out of range");
+    h->mu0 = mu0; h->sigma = sigma; h->s_min = s_min; h->gamma = gamma; h->tau_min = tau_min; h->rho = merit_rho;
+    return NMPC_OK;
+}
+
+int nmpc_shift_warm_start(void* handle, int B, int shift, float* X, float* U, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !X || !U) return fail(h, NMPC_E_ARG, "null argument");
+    if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (shift < 0) return fail(h, NMPC_E_ARG, "negative shift");
+    if (shift == 0 || B == 0) return NMPC_OK;
+    const int N = h->dims.N;
+    if (shift > N) shift = N;
+    if ((size_t)N * h->nx > 256 * 16 || (size_t)N * h->nu > 256 * 16)
+        return fail(h, NMPC_E_ARG, "trajectory too long for the shift kernel");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(nmpc::nmpc_shift_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, h->nx, h->nu, shift, X, U);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, int yref_per_stage,
+                     const float* yref_e, const float* params, float* X, float* U, int* status,
+                     float* stats, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (!x0 || !yref || !yref_e || !X || !U || (h->np > 0 && !params)) return fail(h, NMPC_E_ARG, "null argument");
+    if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
+    if (B == 0) return NMPC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->ws_dirty) {
+        HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
+        h->ws_dirty = false;
+    }
+    nmpc::SolveArgs a{};
+    a.mp = h->mp;
+    std::memcpy(a.W, h->W, sizeof(a.W));
+    std::memcpy(a.We, h->We, sizeof(a.We));
+    a.reg = h->reg; a.reg_e = h->reg_e;
+    a.N = h->dims.N; a.B = B;
+    a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm; a.line_search = h->line_search;
+    a.yref_per_stage = yref_per_stage ? 1 : 0;
+    a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
+    a.gamma = h->gamma; a.tau_min = h->tau_min; a.rho = h->rho;
+    a.x0 = x0; a.yref = yref; a.yref_e = yref_e; a.params = params ? params : x0;
+    a.X = X; a.U = U; a.status = status; a.stats = stats; a.ws = h->ws;
+    if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return launch_solve<nmpc::DoubleIntegrator>(h, a, st);
+    return launch_solve<nmpc::Centroidal>(h, a, st);
+}
+
+int nmpc_riccati_batch(void* handle, int Bsz, int nx, int nu, const float* Q, const float* R,
+                       const float* q, const float* r, const float* A, const float* B_,
+                       const float* d, const float* dx0, float* dX, float* dU, int* status,
+                       void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (!Q || !R || !q || !r || !A || !B_ || !d || !dx0 || !dX || !dU) return fail(h, NMPC_E_ARG, "null argument");
+    if (nx < 1 || nx > 15 || nu < 1 || nu > 16) return fail(h, NMPC_E_ARG, "need 1 <= nx <= 15, 1 <= nu <= 16");
+    if (Bsz < 0 || Bsz > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (Bsz == 0) return NMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::RiccatiArgs a{h->dims.N, Bsz, nx, nu, Q, R, q, r, A, B_, d, dx0, dX, dU, status, h->ws};
+    h->ws_dirty = true;
+    hipLaunchKernelGGL(nmpc::nmpc_riccati_kernel, dim3(Bsz), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, const float* S_nom,
+                        float* err, float* weight, float threshold, float ood_weight, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!S || !S_nom || !err) return fail(h, NMPC_E_ARG, "null argument");
+    if (B < 0 || T < 1 || ns < 2) return fail(h, NMPC_E_ARG, "need B >= 0, T >= 1, ns >= 2");
+    if (B == 0) return NMPC_OK;
+    const size_t lds = (size_t)nmpc::TRB * (ns | 1) * sizeof(float);
+    if (lds > 64 * 1024) return fail(h, NMPC_E_ARG, "state dimension too large for the staging tile");
+    const long long rows = (long long)B * T;
+    const long long blocks = (rows + nmpc::TRB - 1) / nmpc::TRB;
+    if (blocks > 0x7fffffffLL) return fail(h, NMPC_E_ARG, "too many rows");
+    hipLaunchKernelGGL(nmpc::nmpc_tracking_error_kernel, dim3((unsigned)blocks), dim3(nmpc::TRB), lds,
+                       static_cast<hipStream_t>(stream), rows, T, ns, S, S_nom, err, weight, threshold,
+                       ood_weight);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !out_host) return fail(h, NMPC_E_ARG, "null argument");
+    if (b < 0 || b >= h->dims.B_max || k < 0 || k >= h->dims.N || which < 0 || which > 2)
+        return fail(h, NMPC_E_ARG, "index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const size_t N = h->dims.N;
+    const float* src = h->ws + ((size_t)b * 3 * N + (size_t)which * N + k) * nmpc::TILE;
+    HIP_TRY(h, hipMemcpy(out_host, src, nmpc::TILE * sizeof(float), hipMemcpyDeviceToHost));
+    return NMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// nmpc_tile.hpp -- 16x16 fp32 tile algebra for one wavefront (gfx950 / CDNA4).
+//
+// One NMPC problem lives in one 64-lane wavefront.  Every matrix of the Riccati recursion
+// (nx+1 <= 16, nu <= 16) is a 16x16 fp32 tile held in the *accumulator layout* of
+// v_mfma_f32_16x16x4_f32: lane l = 16*q + c owns rows 4q..4q+3 of column c (4 VGPRs).
+//
+// The only product needed is  X'Y  and the accumulator layout feeds it with no data movement:
+// with the K index permuted as k = 4q + s (s = MFMA step), lane (q,c) register s of a tile T is
+// T[4q+s][c], which is exactly the B-operand of step s for "...* T" and the A-operand of step s
+// for "T' * ...".  So   xty(X, Y) = X'Y   is four MFMAs on registers the wave already holds.
+// (fp32-input MFMA is exact fp32, a k-ordered fmaf chain: cdna_hip_programming.md section 3.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nmpc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TS = 16;        // tile side
+constexpr int TILE = TS * TS; // floats per tile (column-major image: element (i,c) at c*16+i)
+constexpr int LDC = 20;       // LDS column stride (floats) of a conversion tile: 80 B keeps
+                              // ds_read_b128 of 16 different columns conflict-free
+constexpr int CTILE = TS * LDC;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// C + X'Y  (all three in accumulator layout)
+__device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y, f32x4 C) {
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], C, 0, 0, 0);
+    return C;
+}
+__device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y) { return xty(X, Y, zero4()); }
+
+// wave-uniform value of lane `src` (src must be a compile-time constant after unrolling)
+__device__ __forceinline__ float bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// 1/d: v_rcp_f32 plus one Newton step (off the IEEE divide expansion, ~1 ulp)
+__device__ __forceinline__ float fast_rcp(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+
+// ---- global <-> accumulator layout (tile image is column-major, 1 KiB, 16 B aligned) --------
+__device__ __forceinline__ f32x4 load_tile(const float* __restrict__ t, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    return *reinterpret_cast<const f32x4*>(t + c * TS + 4 * q);
+}
+__device__ __forceinline__ void store_tile(float* __restrict__ t, int lane, f32x4 v) {
+    const int q = lane >> 4, c = lane & 15;
+    *reinterpret_cast<f32x4*>(t + c * TS + 4 * q) = v;
+}
+// accumulator layout of the TRANSPOSE of the stored tile: 4 dword loads, each 64 B contiguous
+__device__ __forceinline__ f32x4 load_tile_t(const float* __restrict__ t, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    f32x4 v;
+    v[0] = t[(4 * q + 0) * TS + c];
+    v[1] = t[(4 * q + 1) * TS + c];
+    v[2] = t[(4 * q + 2) * TS + c];
+    v[3] = t[(4 * q + 3) * TS + c];
+    return v;
+}
+
+// ---- LDS conversion tiles (column stride LDC) ----------------------------------------------
+__device__ __forceinline__ void lds_store_acc(float* t, int lane, f32x4 v) {
+    const int q = lane >> 4, c = lane & 15;
+    *reinterpret_cast<f32x4*>(t + c * LDC + 4 * q) = v;
+}
+__device__ __forceinline__ f32x4 lds_load_acc(const float* t, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    return *reinterpret_cast<const f32x4*>(t + c * LDC + 4 * q);
+}
+
+// ---- LDL' elimination in column layout ------------------------------------------------------
+// Lane L < 16 holds column L of Huu (symmetric), lanes 16..31 the columns of [Hux | hu],
+// lanes 32..47 the columns of I.  After the sweep every right-hand-side lane holds
+//   col[j] = (D^-1/2 L^-1 rhs)[j]      i.e.  Y = D^-1/2 L^-1 [Hux|hu],  W = D^-1/2 L^-1,
+// so that  Huu^-1 = W'W,  K = -W'Y,  P+ = Hxx - Y'Y  need no back substitution.
+// All cross-lane traffic is v_readlane of lane j's registers (wave-uniform scalars).
+// Returns false if a pivot is not positive (status "QP failure").
+template <int NU>
+__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const float d = bcast(col[j], j);
+        ok = ok && (d > 0.0f);
+        const float rinv = fast_rcp(d);
+        const float w = col[j] * rinv;
+#pragma unroll
+        for (int i = j + 1; i < NU; ++i) {
+            const float l = bcast(col[i], j);
+            col[i] = fmaf(-l, w, col[i]);
+        }
+        col[j] = col[j] * __builtin_amdgcn_rsqf(d);
+    }
+    return ok;
+}
+
+// wave reductions (64 lanes)
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace nmpc

@@ -1,0 +1,68 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/nmpc.h declares.
+No compute calls here (they need a device); argument validation that is decided on the host is checked."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from iterative_learning_nmpc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from iterative_learning_nmpc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "nmpc.h")).read()
+    declared = set(re.findall(r"\b(nmpc_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_model_dims(lib):
+    v = [ctypes.c_int() for _ in range(4)]
+    assert lib.nmpc_model_dims(1, *[ctypes.byref(x) for x in v]) == 0
+    assert [x.value for x in v] == [12, 12, 16, 16]
+    assert lib.nmpc_model_dims(0, *[ctypes.byref(x) for x in v]) == 0
+    assert [x.value for x in v] == [4, 2, 0, 4]
+    assert lib.nmpc_model_dims(9, None, None, None, None) == -1
+    assert lib.nmpc_model_dims(1, None, None, None, None) == 0       # out pointers are optional
+
+
+def test_create_rejects_bad_dims_on_the_host(lib):
+    from iterative_learning_nmpc_amd import _lib
+    h = ctypes.c_void_p()
+    for dims in (_lib.NmpcDims(5, 50, 8, 0), _lib.NmpcDims(1, 0, 8, 0), _lib.NmpcDims(1, 50, 0, 0),
+                 _lib.NmpcDims(1, 50, 8, 3)):
+        assert lib.nmpc_create(ctypes.byref(dims), 0, ctypes.byref(h)) == -1
+        assert not h.value and lib.nmpc_last_error(None)
+    assert lib.nmpc_create(None, 0, ctypes.byref(h)) == -1
+
+
+def test_python_layer_refuses_to_run_without_a_device():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        BatchedNmpcSolver(1, 50, 4)
+
+
+def test_product_never_imports_the_oracle():
+    """No import, include, link or path reference to oracle/ anywhere in the shipped package."""
+    pkg = os.path.join(ROOT, "iterative_learning_nmpc_amd")
+    bad = re.compile(r"^\s*(from|import)\s+oracle\b|#\s*include[^\n]*oracle|liboracle|oracle[/\\.]", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".inc", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(text), os.path.join(dirpath, f)

@@ -1,0 +1,236 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative L2 on trajectories.  It is asserted against the
+fp64 oracle where the fp32 arithmetic allows it and otherwise against the fp32 oracle, with the
+measured fp32-vs-fp64 floor quoted next to each bound.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _solver(w, B, dev, **opts):
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    s = BatchedNmpcSolver(w.model_id, w.N, B, dev)
+    s.set_model_params(w.mp)
+    s.set_cost_weights(w.W, w.W_e, w.meta.get("reg", 1e-6), w.meta.get("reg_e", 1e-5))
+    s.set_max_iter(opts.get("max_sqp_iter", 1))
+    s.set_max_qp_iter(opts.get("n_ipm", 6))
+    s.set_nlp_tol(opts.get("nlp_tol", 0.0))
+    s.set_line_search(opts.get("line_search", 0))
+    return s
+
+
+def _gpu_solve(s, w):
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+    X, U, st, stats = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"])
+    torch.cuda.synchronize()
+    return X.cpu().numpy(), U.cpu().numpy(), st.cpu().numpy(), stats.cpu().numpy()
+
+
+def _oracle_solve(o, w, **opts):
+    kw = dict(max_sqp_iter=1, n_ipm=6, yref_per_stage=1, reg=w.meta.get("reg", 1e-6),
+              reg_e=w.meta.get("reg_e", 1e-5))
+    kw.update(opts)
+    return o.solve_batch(w.model_id, w.N, w.mp, o.opt(**kw), w.W, w.W_e, w.x0, w.yref, w.yref_e,
+                         w.params, w.X, w.U)
+
+
+# ------------------------------------------------------------------------------- LQ core
+@pytest.mark.parametrize("nx,nu,N", [(12, 12, 50), (4, 2, 20), (7, 5, 13), (15, 16, 9), (1, 1, 3)])
+def test_riccati_matches_oracle(dev, oracle64, nx, nu, N):
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    from iterative_learning_nmpc_amd.workloads import MODEL_CENTROIDAL
+    rng = np.random.default_rng(nx * 100 + nu)
+    B = 8
+    def spd(n, m):
+        M = rng.normal(0, 1, (B, m, n, n))
+        return M @ M.transpose(0, 1, 3, 2) / n + np.eye(n) * 0.5
+    Q, R = spd(nx, N + 1), spd(nu, N)
+    q, r = rng.normal(0, 1, (B, N + 1, nx)), rng.normal(0, 1, (B, N, nu))
+    A = np.eye(nx) + rng.normal(0, 0.3, (B, N, nx, nx)) / np.sqrt(nx)
+    Bm = rng.normal(0, 0.5, (B, N, nx, nu))
+    d, dx0 = rng.normal(0, 0.1, (B, N, nx)), rng.normal(0, 1, (B, nx))
+    s = BatchedNmpcSolver(MODEL_CENTROIDAL, N, B, dev)
+    args = [s.to_device(a) for a in (Q, R, q, r, A, Bm, d, dx0)]
+    dX, dU, st = s.riccati(*args)
+    torch.cuda.synchronize()
+    dX, dU, st = dX.cpu().numpy(), dU.cpu().numpy(), st.cpu().numpy()
+    assert (st == 0).all()
+    for b in range(B):
+        ref = oracle64.riccati(Q[b], R[b], q[b], r[b], A[b], Bm[b], d[b], dx0[b])
+        assert ref["status"] == 0
+        assert rel(dX[b], ref["dX"]) < 2e-5, (b, rel(dX[b], ref["dX"]))
+        assert rel(dU[b], ref["dU"]) < 2e-5, (b, rel(dU[b], ref["dU"]))
+
+
+def test_riccati_flags_indefinite_pivot(dev):
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    N, nx, nu, B = 4, 3, 2, 2
+    s = BatchedNmpcSolver(0, N, B, dev)
+    Q = np.tile(np.eye(nx), (B, N + 1, 1, 1))
+    R = np.tile(np.eye(nu), (B, N, 1, 1))
+    R[1, 2] = -10 * np.eye(nu)          # problem 1 has a negative-definite input weight
+    z = lambda *sh: np.zeros(sh)
+    A = np.tile(np.eye(nx), (B, N, 1, 1))
+    Bm = np.ones((B, N, nx, nu)) * 0.1
+    args = [s.to_device(a) for a in (Q, R, z(B, N + 1, nx), z(B, N, nu), A, Bm, z(B, N, nx), np.ones((B, nx)))]
+    _, _, st = s.riccati(*args)
+    assert st.cpu().numpy().tolist() == [0, 4]
+
+
+# ------------------------------------------------------------------------------- linearisation
+def test_centroidal_stage_tiles_match_oracle(dev, oracle64):
+    from iterative_learning_nmpc_amd import workloads as wl
+    w = wl.centroidal_trot(B=4, N=50, seed=3)
+    w.X += np.random.default_rng(0).normal(0, 0.02, w.X.shape)     # non-trivial defects
+    s = _solver(w, 4, dev, n_ipm=0)
+    _gpu_solve(s, w)
+    for b in (0, 3):
+        for k in (0, 17, 49):
+            xn, A, Bj = oracle64.dynamics(1, w.mp, w.X[b, k], w.U[b, k], w.params[b, k])
+            At, Bt = s.debug_tile(b, k, 0), s.debug_tile(b, k, 1)
+            assert np.abs(At[:12, :12] - A).max() < 2e-5 * max(1.0, np.abs(A).max())
+            assert np.abs(Bt[:12, :12] - Bj).max() < 2e-5 * max(1.0, np.abs(Bj).max())
+            assert np.abs(At[:12, 12] - (xn - w.X[b, k + 1])).max() < 1e-5
+            assert At[12, 12] == 1.0 and np.all(At[12, :12] == 0) and np.all(At[13:, :] == 0)
+            assert np.all(Bt[12:, :] == 0) and np.all(Bt[:, 12:] == 0)
+
+
+# ------------------------------------------------------------------------------- full solves
+def test_double_integrator_lq_exact(dev, oracle64):
+    """Config 1: an LQ problem, one SQP iteration is the exact optimum."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    w = wl.double_integrator(B=16, N=20, seed=0)
+    s = _solver(w, 16, dev, n_ipm=0)
+    X, U, st, stats = _gpu_solve(s, w)
+    Xo, Uo, sto, _ = _oracle_solve(oracle64, w, n_ipm=0)
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5
+    assert (st == 2).all() and (sto == 2).all()
+    # a second iteration does not move the solution: converged -> status 0 with a tolerance
+    s.set_max_iter(3); s.set_nlp_tol(1e-3)
+    X2, U2, st2, stats2 = _gpu_solve(s, w)
+    assert (st2 == 0).all() and (stats2[:, 3] == 2).all()
+    assert rel(X2, Xo) < 1e-5
+
+
+def test_double_integrator_box_constraints(dev, oracle64, oracle32):
+    from iterative_learning_nmpc_amd import workloads as wl
+    w = wl.double_integrator(B=16, N=20, seed=1, umax=1.0)
+    s = _solver(w, 16, dev, n_ipm=8)
+    X, U, st, _ = _gpu_solve(s, w)
+    Xo, Uo, _, _ = _oracle_solve(oracle64, w, n_ipm=8)
+    assert np.abs(U).max() <= 1.0 + 1e-4          # box respected
+    assert np.abs(Uo).max() > 0.9                   # and it is active
+    assert rel(X, Xo) < 1e-4 and rel(U, Uo) < 1e-4, (rel(X, Xo), rel(U, Uo))
+
+
+@pytest.mark.parametrize("n_ipm,sqp", [(0, 1), (6, 1), (6, 3), (0, 15)])
+def test_centroidal_solve_parity(dev, oracle64, oracle32, n_ipm, sqp):
+    """Config 2 shapes (nx=nu=12, N=50) at a batch the oracle finishes in seconds."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B = 64
+    w = wl.centroidal_trot(B=B, N=50, seed=0)
+    s = _solver(w, B, dev, n_ipm=n_ipm, max_sqp_iter=sqp)
+    X, U, st, stats = _gpu_solve(s, w)
+    X64, U64, st64, stats64 = _oracle_solve(oracle64, w, n_ipm=n_ipm, max_sqp_iter=sqp)
+    X32, U32, _, _ = _oracle_solve(oracle32, w, n_ipm=n_ipm, max_sqp_iter=sqp)
+    floor = max(rel(X32, X64), rel(U32, U64))         # what fp32 itself costs on the CPU
+    eX, eU = rel(X, X64), rel(U, U64)
+    print(f"n_ipm={n_ipm} sqp={sqp}: gpu-vs-f64 X {eX:.2e} U {eU:.2e}; gpu-vs-f32 X {rel(X, X32):.2e} "
+          f"U {rel(U, U32):.2e}; f32-vs-f64 floor {floor:.2e}")
+    assert np.array_equal(st, st64)
+    assert eX < 1e-5 * max(1.0, 2 * sqp) and eU < 1e-5 * max(1.0, 2 * sqp)
+    assert np.allclose(stats[:, 0], stats64[:, 0], rtol=1e-4)       # cost at linearisation
+    assert np.array_equal(stats[:, 3], stats64[:, 3])               # iteration count
+
+
+def test_centroidal_active_friction(dev, oracle64):
+    """Low friction makes the pyramid active: constraints hold, parity at the fp32 floor of an
+    ill-conditioned barrier system (bound documented in DESIGN.md 3.3)."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B = 32
+    w = wl.centroidal_trot(B=B, N=50, seed=1)
+    w.mp[6] = 0.3
+    s = _solver(w, B, dev, n_ipm=6)
+    X, U, st, _ = _gpu_solve(s, w)
+    X64, U64, _, _ = _oracle_solve(oracle64, w, n_ipm=6)
+    f = U.reshape(B, 50, 4, 3)
+    c = np.moveaxis(w.params[:, :50, :4], 2, 2)
+    viol = np.maximum(np.abs(f[..., :2]).max(-1) - 0.3 * f[..., 2], 0) * c
+    assert viol.max() < 1e-3
+    assert rel(X, X64) < 1e-4 and rel(U, U64) < 1e-4, (rel(X, X64), rel(U, U64))
+
+
+def test_centroidal_line_search_and_status(dev, oracle64):
+    from iterative_learning_nmpc_amd import workloads as wl
+    B = 16
+    w = wl.centroidal_trot(B=B, N=50, seed=2, warm="zero")
+    s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2, line_search=1)
+    X, U, st, stats = _gpu_solve(s, w)
+    X64, U64, st64, stats64 = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2, line_search=1)
+    same = stats[:, 2] == stats64[:, 2]                 # identical step lengths chosen
+    assert same.mean() > 0.8
+    assert rel(X[same], X64[same]) < 1e-4
+    # NaN input -> status 1 for that problem only
+    w2 = wl.centroidal_trot(B=4, N=50, seed=5)
+    w2.x0[2, 0] = np.nan
+    s2 = _solver(w2, 4, dev)
+    _, _, st2, _ = _gpu_solve(s2, w2)
+    assert st2.tolist() == [2, 2, 1, 2]
+
+
+def test_warm_start_shift(dev, oracle32):
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    rng = np.random.default_rng(0)
+    B, N = 5, 50
+    s = BatchedNmpcSolver(1, N, B, dev)
+    X, U = rng.normal(size=(B, N + 1, 12)).astype(np.float32), rng.normal(size=(B, N, 12)).astype(np.float32)
+    for shift in (0, 1, 2, 7, 50, 60):
+        Xd, Ud = s.to_device(X), s.to_device(U)
+        s.warm_start_solver(Xd, Ud, shift)
+        Xo, Uo = oracle32.shift_warm_start(X, U, shift)
+        assert np.array_equal(Xd.cpu().numpy(), Xo) and np.array_equal(Ud.cpu().numpy(), Uo)
+
+
+# ------------------------------------------------------------------------------- tracking error
+@pytest.mark.parametrize("B,T,ns", [(5, 60, 44), (3, 1, 2), (7, 129, 13), (64, 500, 44)])
+def test_tracking_error_bit_exact(dev, oracle32, B, T, ns):
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    rng = np.random.default_rng(B + T)
+    Snom = rng.normal(0, 1, (T, ns)).astype(np.float32)
+    S = (Snom[None] + rng.normal(0, 0.62, (B, T, ns))).astype(np.float32)
+    S[:, :, 0] += 100.0
+    err, wgt = tracking_error(torch.from_numpy(S).to(dev), torch.from_numpy(Snom).to(dev))
+    ref = oracle32.tracking_error(S, Snom)
+    assert np.array_equal(err.cpu().numpy(), ref)           # fp32, same operation order: bit-exact
+    assert np.array_equal(wgt.cpu().numpy(), np.where(ref > 4.0, 5.0, 1.0).astype(np.float32))
+
+
+def test_tracking_error_golden_ood_selection(dev, golden_dir):
+    """The OOD samples the reference selects (tests/golden/tracking_error.npz) are the ones whose
+    GPU tracking error exceeds the threshold."""
+    import os
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    g = np.load(os.path.join(golden_dir, "tracking_error.npz"))
+    S, Snom = g["s_pert"].astype(np.float32), g["s_nom"].astype(np.float32)
+    err, wgt = tracking_error(torch.from_numpy(S).to(dev), torch.from_numpy(Snom).to(dev),
+                              threshold=float(g["threshold"]))
+    matched = np.isclose(g["t_pert"], g["t_nom"][None], atol=1e-9)   # rows with a nominal counterpart
+    sel = (wgt.cpu().numpy() == 5.0) & matched
+    margin = np.abs(err.cpu().numpy() - 4.0) > 1e-4                    # ignore fp32 ties at the threshold
+    assert np.array_equal(sel[margin], g["ood_selected"][margin])
