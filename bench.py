@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Throughput harness of the batched NMPC solve path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A step = one pass of the hot path over one batch: warm-start shift by one node + one NMPC solve
+(1 SQP iteration x 6 interior-point Riccati sweeps, the reference's steady-state policy,
+mpc_controller/config/quadruped/mpc_opt.py:25-27) for B = 1024 centroidal problems per GPU
+(BASELINE configs[1]: nx = nu = 12, N = 50, fp32), inputs resident in HBM.  Independent problems
+shard across GPUs with no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line; see DESIGN.md section 6 for the roofline accounting.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from iterative_learning_nmpc_amd import workloads as wl  # noqa: E402
+from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector = fp32-input MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_work(nx, nu, ng, np_, N, n_sweeps):
+    """FLOP and HBM bytes one solve needs algorithmically (SURVEY.md 8d formulas)."""
+    nz, ny = nx + nu, nx + nu
+    f_riccati = N * (7 / 3 * nx ** 3 + 4 * nx * nx * nu + 2 * nx * nu * nu + nu ** 3 / 3)
+    f_fwd = N * 2 * (nu * nx + nx * nz)
+    f_barrier = N * 2 * ng * nu * (nu + 1) if n_sweeps > 1 or ng else 0    # G'DG and G'v
+    f_lin = N * 2 * nx * nz * 3                                            # analytic A,B (c_model ~ 3)
+    flops = n_sweeps * (f_riccati + f_fwd + f_barrier) + f_lin
+    nbytes = 4 * (nx + (N + 1) * nx + N * nu + (N + 1) * np_ + N * ny + nx + (N + 1) * nx + N * nu)
+    return flops, nbytes
+
+
+def cpu_baseline(w, n_ipm, sample):
+    """The CPU oracle (fp64 restatement; the reference's acados solver is not installable here)
+    on all host cores, same workload, bounded sample."""
+    from oracle.oracle import Oracle
+    o = Oracle("f64")
+    sl = slice(0, sample)
+    args = (w.model_id, w.N, w.mp, o.opt(max_sqp_iter=1, n_ipm=n_ipm, yref_per_stage=1, reg=w.meta["reg"], reg_e=w.meta["reg_e"]),
+            w.W, w.W_e, w.x0[sl], w.yref[sl], w.yref_e[sl], w.params[sl], w.X[sl], w.U[sl])
+    threads = o.num_threads()
+    o.solve_batch(*args)                       # warm (page in, thread pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        o.solve_batch(*args)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 50:
+            break
+    dt = time.perf_counter() - t0
+    n1 = min(sample, 128)
+    args1 = args[:6] + tuple(a[:n1] for a in args[6:])
+    t1 = time.perf_counter()
+    o.solve_batch(*args1, nthreads=1)
+    single = (time.perf_counter() - t1) / n1
+    return dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
+                sample=f"{sample} of the {w.B} problems x {reps} repeats, fp64 oracle (OpenMP over problems); "
+                       f"single-thread {single * 1e3:.2f} ms/solve")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--ipm", type=int, default=6)
+    ap.add_argument("--sqp", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    B, N = a.batch, 50
+    w = wl.centroidal_trot(B=B, N=N, seed=1000 * rank)
+    s = BatchedNmpcSolver(w.model_id, N, B, dev)
+    s.set_model_params(w.mp)
+    s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+    s.set_max_iter(a.sqp)
+    s.set_max_qp_iter(a.ipm)
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+
+    def step():
+        s.warm_start_solver(t["X"], t["U"], 1)
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats)
+
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        s.warm_start_solver(t["X"], t["U"], 1)
+        ev[i][0].record()                         # same stream the kernels are launched on
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    bad = int((status == 1).sum().item() + (status == 4).sum().item())
+
+    if rank == 0:
+        n_sweeps = a.ipm if a.ipm > 0 else 1
+        flops, nbytes = algorithmic_work(s.nx, s.nu, s.ng if a.ipm > 0 else 0, s.np, N, n_sweeps)
+        flops *= a.sqp
+        tf = flops * B / (kernel_ms * 1e-3) / 1e12
+        gbs = nbytes * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(f"B{B}_ipm{a.ipm}_sqp{a.sqp}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC solves/sec (horizon-50 centroidal, batch)",
+            "value": world * B * a.steps / elapsed, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 fp32, "
+                                   f"{a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step",
+                       "global_batch": world * B, "horizon": N, "parallelism": f"dp{world} (independent problems, no collective)"},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "kernel": "nmpc_solve_kernel<Centroidal>", "kernel_ms": kernel_ms,
+                         "flops_per_solve": flops, "bytes_per_solve": nbytes,
+                         "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS},
+            "failed_problems": bad,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, a.ipm, min(B, 1024))
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

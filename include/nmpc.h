@@ -130,6 +130,11 @@ int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, cons
  * out_host: float[256].  Synchronises the device. */
 int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
 
+/* Diagnostic builds (-DNMPC_STAMPS) write per-phase cycle counts to dev float[B_max][8]
+ * (linearise, barrier parameter, backward, forward, IPM update, step+write-back, -, -).
+ * Production builds ignore the buffer.  NULL detaches it. */
+int nmpc_debug_set_buffer(void *handle, float *dev_buffer);
+
 #ifdef __cplusplus
 }
 #endif

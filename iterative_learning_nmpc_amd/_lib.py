@@ -7,7 +7,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmpc_hip.so")
+# NMPC_HIP_LIB points diagnostics (tools/) at an alternative build of the same C-ABI
+LIB_PATH = os.environ.get("NMPC_HIP_LIB") or os.path.join(_HERE, "libnmpc_hip.so")
 
 NMPC_OK = 0
 STATUS_NAMES = {0: "ok", 1: "nan", 2: "max_iter", 3: "min_step", 4: "qp_failure"}
@@ -30,6 +31,7 @@ SIGNATURES = {
     "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
+    "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }
 
 

@@ -19,6 +19,7 @@ struct Handle {
     int nx = 0, nu = 0, np = 0, ng = 0;
     float* ws = nullptr;
     size_t ws_bytes = 0;
+    float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
@@ -216,6 +217,7 @@ int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, in
     a.gamma = h->gamma; a.tau_min = h->tau_min; a.rho = h->rho;
     a.x0 = x0; a.yref = yref; a.yref_e = yref_e; a.params = params ? params : x0;
     a.X = X; a.U = U; a.status = status; a.stats = stats; a.ws = h->ws;
+    a.dbg = h->dbg;
     if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return launch_solve<nmpc::DoubleIntegrator>(h, a, st);
     return launch_solve<nmpc::Centroidal>(h, a, st);
 }
@@ -253,6 +255,13 @@ int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, cons
                        static_cast<hipStream_t>(stream), rows, T, ns, S, S_nom, err, weight, threshold,
                        ood_weight);
     HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_debug_set_buffer(void* handle, float* dev_buffer) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    h->dbg = dev_buffer;
     return NMPC_OK;
 }
 

@@ -34,9 +34,20 @@ struct SolveArgs {
     int* status;
     float* stats;
     float* ws;            // workspace: per problem 3*N tiles (A~, B~, K~)
+    float* dbg;           // diagnostic builds: [B][8] phase cycle counts, else unused
 };
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
+
+// Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
+// a buffer of their own; the production kernel contains no stamp.
+#ifdef NMPC_STAMPS
+#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const unsigned long long st_t1 = __builtin_readcyclecounter(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#endif
 
 template <class M>
 struct Lds {
@@ -107,6 +118,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     __syncthreads();
 
     int status = NMPC_STATUS_MAXITER;
+    STAMP_DECL;
     float cost = 0.0f, stepn = 0.0f, alpha = 1.0f;
     int it = 0;
     for (it = 0; it < a.max_sqp; ++it) {
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
         __threadfence_block();
         __syncthreads();
 
+        STAMP(0);
         // ------------------------------------------------------------ QP: interior point loop
         const bool use_ipm = (a.n_ipm > 0) && (n_act > 0);
         const int n_sweeps = use_ipm ? a.n_ipm : 1;
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 }
                 tau = fmaxf(a.sigma * wave_sum(m_l) / (float)n_act, a.tau_min);
             }
+            STAMP(1);
             // -------------------------------------------------------- phase R: backward sweep
             f32x4 P;
             {   // terminal: P~ = [diag(We)+reg_e, q_N; q_N', 0]
@@ -256,6 +270,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             }
             __threadfence_block();
             __syncthreads();
+            STAMP(2);
             // -------------------------------------------------------- phase F: forward sweep
             float* oX = use_ipm ? dXp : dX;
             float* oU = use_ipm ? dUp : dU;
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 }
             }
             __syncthreads();
+            STAMP(3);
             // -------------------------------------------------------- phase I: IPM update
             if (use_ipm) {
                 float ap_l = 1.0f, ad_l = 1.0f;
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 __syncthreads();
             }
         }
+        STAMP(4);
         // ------------------------------------------------------------ phase S: step
         float sn_l = 0.0f;
         bool bad_l = false;
@@ -403,6 +420,11 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     }
     for (int i = lane; i < (N + 1) * NX; i += 64) Xg[i] = Xs[i];
     for (int i = lane; i < N * NU; i += 64) Ug[i] = Us[i];
+    STAMP(5);
+#ifdef NMPC_STAMPS
+    if (lane == 0 && a.dbg)
+        for (int i = 0; i < 8; ++i) a.dbg[8 * b + i] = (float)st_acc[i];
+#endif
     if (lane == 0) {
         if (a.status) a.status[b] = status;
         if (a.stats) {

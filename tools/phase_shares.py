@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a solve spends its cycles.  Builds a stamped variant of the library
+(-DNMPC_STAMPS) into gpurun_out/, runs one batch and prints the share of each phase.
+Read SHARES, not lengths: the stamps forbid overlaps the production kernel has."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "gpurun_out", "libnmpc_hip_stamps.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNMPC_STAMPS",
+                "-o", out, os.path.join(ROOT, "iterative_learning_nmpc_amd", "csrc", "nmpc_api.hip")], check=True)
+os.environ["NMPC_HIP_LIB"] = out
+sys.path.insert(0, ROOT)
+import ctypes  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from iterative_learning_nmpc_amd import workloads as wl  # noqa: E402
+from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+w = wl.centroidal_trot(B=B, N=50, seed=0)
+s = BatchedNmpcSolver(w.model_id, w.N, B, "cuda:0")
+s.set_model_params(w.mp)
+s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+dbg = torch.zeros(B, 8, device="cuda:0")
+s.lib.nmpc_debug_set_buffer(s._h, ctypes.c_void_p(dbg.data_ptr()))
+t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+for _ in range(3):
+    s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"])
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().astype(np.float64)
+names = ["linearise", "barrier tau", "backward", "forward", "ipm update", "step+store"]
+tot = d[:, :6].sum(1).mean()
+print(f"B={B}: mean cycles per wave {tot:.0f}")
+for i, n in enumerate(names):
+    print(f"  {n:12s} {d[:, i].mean():10.0f} cycles  {100 * d[:, i].mean() / tot:5.1f} %")
