@@ -126,7 +126,8 @@ int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, cons
                         float *err, float *weight, float threshold, float ood_weight, void *stream);
 
 /* Test hook: copy one stage tile of problem b out of the workspace after a solve.
- * which: 0 = A~ (16x16, column-major, [A d; 0 1]), 1 = B~, 2 = K~ = [K kff] of the last sweep.
+ * which: 0 = A~ (16x16, column-major, [A d; 0 1]), 1 = B~, 2 = K~ = [K kff] and 3 = A~ + B~K~ of the
+ * last sweep (both row-major).
  * out_host: float[256].  Synchronises the device. */
 int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
 

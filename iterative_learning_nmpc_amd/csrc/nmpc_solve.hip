@@ -39,6 +39,9 @@ struct SolveArgs {
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
+constexpr int WS_TILES = 4;        // workspace tiles per stage: A~, B~, K~', Acl~'
+constexpr int N_LANE_STAGES = 2;   // lane = stage phases keep per-stage data in registers: N <= 128
+
 // Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
 // a buffer of their own; the production kernel contains no stamp.
 #ifdef NMPC_STAMPS
@@ -49,24 +52,30 @@ __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 #define STAMP(i)
 #endif
 
+// LDS layout of one problem.  Every per-stage array is FEATURE-major, [feature][stage] with an odd
+// stage stride NS: the lane = stage phases touch consecutive banks, and the stage sweeps (lanes
+// differ in the feature) stay conflict-free because NS is odd.
 template <class M>
 struct Lds {
-    // offsets in floats
-    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, cv, act, conv, total;
+    int NS;   // stage stride (odd, >= N+1)
+    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, cv, gsq, gvt, act, conv, total;   // float offsets
     __host__ __device__ explicit Lds(int N) {
+        NS = (N + 1) | 1;
         int o = 0;
-        Xs = o;  o += round4((N + 1) * M::NX);
-        Us = o;  o += round4(N * M::NU);
-        dX = o;  o += round4((N + 1) * M::NX);
-        dU = o;  o += round4(N * M::NU);
-        dXp = o; o += round4((N + 1) * M::NX);
-        dUp = o; o += round4(N * M::NU);
-        qv = o;  o += round4((N + 1) * M::NX);
-        rv = o;  o += round4(N * M::NU);
-        sv = o;  o += round4(N * M::NG);
-        lv = o;  o += round4(N * M::NG);
-        cv = o;  o += round4(N * M::NG);
-        act = o; o += round4(N);
+        Xs = o;  o += round4(M::NX * NS);
+        Us = o;  o += round4(M::NU * NS);
+        dX = o;  o += round4(M::NX * NS);
+        dU = o;  o += round4(M::NU * NS);
+        dXp = o; o += round4(M::NX * NS);
+        dUp = o; o += round4(M::NU * NS);
+        qv = o;  o += round4(M::NX * NS);
+        rv = o;  o += round4(M::NU * NS);
+        sv = o;  o += round4(M::NG * NS);
+        lv = o;  o += round4(M::NG * NS);
+        cv = o;  o += round4(M::NG * NS);
+        gsq = o; o += round4(M::NG * NS);
+        gvt = o; o += round4(M::NG * NS);
+        act = o; o += round4(NS);
         conv = o; o += 2 * CTILE;
         total = o;
     }
@@ -91,13 +100,16 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     const int q4 = lane >> 4, c = lane & 15;
     const int N = a.N;
     const Lds<M> L(N);
+    const int NS = L.NS;
     float* Xs = smem + L.Xs;   float* Us = smem + L.Us;
     float* dX = smem + L.dX;   float* dU = smem + L.dU;
     float* dXp = smem + L.dXp; float* dUp = smem + L.dUp;
     float* qv = smem + L.qv;   float* rv = smem + L.rv;
     float* sv = smem + L.sv;   float* lv = smem + L.lv;   float* cv = smem + L.cv;
+    float* gsq = smem + L.gsq; float* gvt = smem + L.gvt;
     unsigned* actm = reinterpret_cast<unsigned*>(smem + L.act);
     float* conv = smem + L.conv;
+#define AT(arr, k, i) (arr)[(i) * NS + (k)]
 
     float* Xg = a.X + (size_t)b * (N + 1) * NX;
     float* Ug = a.U + (size_t)b * N * NU;
@@ -105,17 +117,20 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     const float* yr = a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY);
     const float* yre = a.yref_e + (size_t)b * NX;
     const float* x0 = a.x0 + (size_t)b * NX;
-    float* At = a.ws + (size_t)b * 3 * N * TILE;
+    float* At = a.ws + (size_t)b * WS_TILES * N * TILE;
     float* Bt = At + (size_t)N * TILE;
-    float* Kt = Bt + (size_t)N * TILE;
+    float* Kt = Bt + (size_t)N * TILE;   // transposed images of K~
+    float* Ct = Kt + (size_t)N * TILE;   // transposed images of Acl~ = A~ + B~K~
 
-    for (int i = lane; i < (N + 1) * NX; i += 64) Xs[i] = Xg[i];
-    for (int i = lane; i < N * NU; i += 64) Us[i] = Ug[i];
+    for (int i = lane; i < L.conv; i += 64) smem[i] = 0.0f;   // padding entries stay finite
+    wave_sync();
+    for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; AT(Xs, k, e - k * NX) = Xg[e]; }
+    for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; AT(Us, k, e - k * NU) = Ug[e]; }
     // per-lane weights of "its" column
     const float wq_c = (c < NX) ? a.W[c] + a.reg : 0.0f;
     const float wr_c = (c < NU) ? a.W[NX + (c < NU ? c : 0)] + a.reg : 0.0f;
     const float we_c = (c < NX) ? a.We[c < NX ? c : 0] + a.reg_e : 0.0f;
-    __syncthreads();
+    wave_sync();
 
     int status = NMPC_STATUS_MAXITER;
     STAMP_DECL;
@@ -123,14 +138,14 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     int it = 0;
     for (it = 0; it < a.max_sqp; ++it) {
         // ------------------------------------------------------------ phase L: linearise
-        float cost_l = 0.0f;
+        float cost_l = 0.0f, mu_l = 0.0f;
         int nact_l = 0;
         for (int k = lane; k < N; k += 64) {
             float x[NX], u[NU], xn[NX], p[NP > 0 ? NP : 1];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = Xs[k * NX + i];
+            for (int i = 0; i < NX; ++i) x[i] = AT(Xs, k, i);
 #pragma unroll
-            for (int i = 0; i < NU; ++i) u[i] = Us[k * NU + i];
+            for (int i = 0; i < NU; ++i) u[i] = AT(Us, k, i);
 #pragma unroll
             for (int i = 0; i < NP; ++i) p[i] = pg[(size_t)k * NP + i];
             float* Atk = At + (size_t)k * TILE;
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 float v[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xs[(k + 1) * NX + (i < NX ? i : 0)]
+                    v[i] = (i < NX) ? xn[i < NX ? i : 0] - AT(Xs, k + 1, i < NX ? i : 0)
                                     : (i == NX ? 1.0f : 0.0f);
                 store_col16(Atk, NX, v, NQ);
             }
@@ -160,13 +175,13 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const float e = x[i] - yk[i];
-                qv[k * NX + i] = a.W[i] * e;
+                AT(qv, k, i) = a.W[i] * e;
                 cost_l += 0.5f * a.W[i] * e * e;
             }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const float e = u[i] - yk[NX + i];
-                rv[k * NU + i] = a.W[NX + i] * e;
+                AT(rv, k, i) = a.W[NX + i] * e;
                 cost_l += 0.5f * a.W[NX + i] * e * e;
             }
             if (a.n_ipm > 0) {
@@ -179,99 +194,134 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 for (int j = 0; j < NG; ++j) {
                     const float cj = g[j] - M::h(a.mp, j);
                     const float s = fmaxf(-cj, a.s_min);
-                    cv[k * NG + j] = cj;
-                    sv[k * NG + j] = s;
-                    lv[k * NG + j] = a.mu0 / s;
+                    AT(cv, k, j) = cj;
+                    AT(sv, k, j) = s;
+                    AT(lv, k, j) = a.mu0 / s;
+                    if ((am >> j) & 1u) mu_l += a.mu0;      // s * (mu0 / s)
                 }
             }
         }
         if (lane < NX) {
-            const float e = Xs[N * NX + lane] - yre[lane];
-            qv[N * NX + lane] = a.We[lane] * e;
+            const float e = AT(Xs, N, lane) - yre[lane];
+            AT(qv, N, lane) = a.We[lane] * e;
             cost_l += 0.5f * a.We[lane] * e * e;
         }
-        for (int i = lane; i < (N + 1) * NX; i += 64) dX[i] = 0.0f;
-        for (int i = lane; i < N * NU; i += 64) dU[i] = 0.0f;
+        for (int i = lane; i < NX * NS; i += 64) dX[i] = 0.0f;
+        for (int i = lane; i < NU * NS; i += 64) dU[i] = 0.0f;
         cost = wave_sum(cost_l);
         const int n_act = (int)(wave_sum((float)nact_l) + 0.5f);
         // make the tile stores of this wave visible to its own later loads
         __threadfence_block();
-        __syncthreads();
+        wave_sync();
 
         STAMP(0);
         // ------------------------------------------------------------ QP: interior point loop
         const bool use_ipm = (a.n_ipm > 0) && (n_act > 0);
         const int n_sweeps = use_ipm ? a.n_ipm : 1;
         bool qp_ok = true;
+        float mu_sum = wave_sum(mu_l);          // sum of s.lam over the active rows
         for (int ii = 0; ii < n_sweeps; ++ii) {
             float tau = 0.0f;
             if (use_ipm) {
-                float m_l = 0.0f;
+                // barrier coefficients of this iteration, lane = stage:
+                //   D = lam/s, gsq = sqrt(D), gvt = (tau/s + lam + D c)/sqrt(D)
+                // so that the stage sweep only builds Gs = gsq.G and Vt = gvt.e_nx (no divides there)
+                tau = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
                 for (int k = lane; k < N; k += 64) {
                     const unsigned am = actm[k];
 #pragma unroll
-                    for (int j = 0; j < NG; ++j)
-                        if ((am >> j) & 1u) m_l += sv[k * NG + j] * lv[k * NG + j];
+                    for (int j = 0; j < NG; ++j) {
+                        const bool on = (am >> j) & 1u;
+                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = AT(cv, k, j);
+                        const float is = fast_rcp(s);
+                        const float D = l * is;
+                        const float rs = __builtin_amdgcn_rsqf(D);
+                        AT(gsq, k, j) = on ? D * rs : 0.0f;
+                        AT(gvt, k, j) = on ? (tau * is + l + D * cj) * rs : 0.0f;
+                    }
                 }
-                tau = fmaxf(a.sigma * wave_sum(m_l) / (float)n_act, a.tau_min);
+                wave_sync();
             }
             STAMP(1);
             // -------------------------------------------------------- phase R: backward sweep
             f32x4 P;
             {   // terminal: P~ = [diag(We)+reg_e, q_N; q_N', 0]
-                const float qc = (c < NX) ? qv[N * NX + (c < NX ? c : 0)] : 0.0f;
+                const float qc = (c < NX) ? AT(qv, N, c < NX ? c : 0) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * q4 + r;
                     float v = 0.0f;
                     if (row == c && row < NX) v = we_c;
-                    if (c == NX && row < NX) v = qv[N * NX + (row < NX ? row : 0)];
+                    if (c == NX && row < NX) v = AT(qv, N, row < NX ? row : 0);
                     if (row == NX && c < NX) v = qc;
                     P[r] = v;
                 }
             }
-            for (int k = N - 1; k >= 0; --k) {
-                const f32x4 Aa = load_tile(At + (size_t)k * TILE, lane);
-                const f32x4 Ba = load_tile(Bt + (size_t)k * TILE, lane);
-                f32x4 Qt, St, Rt;
-                const float qc = (c < NX) ? qv[k * NX + (c < NX ? c : 0)] : 0.0f;
+            // Stage tiles are prefetched TWO stages ahead.  The wave is alone on its SIMD at
+            // B = 1024, so nothing else hides the L2 / Infinity-Cache latency; and because vmcnt
+            // retires in issue order, a distance of two keeps each stage's K~/Acl~ stores
+            // younger than the loads the next stage waits for (no stall on store completion).
+            f32x4 Ar[2], Br[2], Tr[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q4 + r;
-                    float vq = 0.0f;
-                    if (row == c && row < NX) vq = wq_c;
-                    if (c == NX && row < NX) vq = qv[k * NX + (row < NX ? row : 0)];
-                    if (row == NX && c < NX) vq = qc;
-                    Qt[r] = vq;
-                    St[r] = (c == NX && row < NU) ? rv[k * NU + (row < NU ? row : 0)] : 0.0f;
-                    Rt[r] = (row == c && row < NU) ? wr_c : 0.0f;
-                }
-                if (use_ipm) {
-                    const unsigned am = actm[k];
-                    f32x4 Gs, Vt;
+            for (int j = 0; j < 2; ++j) {
+                const int kk = (N - 1 - j > 0) ? N - 1 - j : 0;
+                Ar[j] = load_tile(At + (size_t)kk * TILE, lane);
+                Br[j] = load_tile(Bt + (size_t)kk * TILE, lane);
+                Tr[j] = load_tile_t(Bt + (size_t)kk * TILE, lane);
+            }
+            for (int k0 = N - 1; k0 >= 0; k0 -= 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = k0 - j;
+                    if (k < 0) break;
+                    const f32x4 Aa = Ar[j], Ba = Br[j], Bta = Tr[j];
+                    const int kn = (k - 2 > 0) ? k - 2 : 0;
+                    Ar[j] = load_tile(At + (size_t)kn * TILE, lane);
+                    Br[j] = load_tile(Bt + (size_t)kn * TILE, lane);
+                    Tr[j] = load_tile_t(Bt + (size_t)kn * TILE, lane);
+                    f32x4 Qt, St, Rt;
+                    const float qc = (c < NX) ? AT(qv, k, c < NX ? c : 0) : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = 4 * q4 + r;
-                        const bool on = (j < NG) && ((am >> j) & 1u);
-                        const int jj = (j < NG) ? j : 0;
-                        const float s = sv[k * NG + jj], l = lv[k * NG + jj], cj = cv[k * NG + jj];
-                        const float D = on ? l / s : 0.0f;
-                        const float sq = sqrtf(D);
-                        const float vj = on ? (tau / s + l + D * cj) : 0.0f;
-                        Gs[r] = (on && c < NU) ? M::G(a.mp, jj, c) * sq : 0.0f;
-                        Vt[r] = (on && c == NX) ? vj / sq : 0.0f;
+                        const int row = 4 * q4 + r;
+                        float vq = 0.0f;
+                        if (row == c && row < NX) vq = wq_c;
+                        if (c == NX && row < NX) vq = AT(qv, k, row < NX ? row : 0);
+                        if (row == NX && c < NX) vq = qc;
+                        Qt[r] = vq;
+                        St[r] = (c == NX && row < NU) ? AT(rv, k, row < NU ? row : 0) : 0.0f;
+                        Rt[r] = (row == c && row < NU) ? wr_c : 0.0f;
                     }
-                    Rt = xty(Gs, Gs, Rt);
-                    St = xty(Gs, Vt, St);
+                    if (use_ipm) {
+                        f32x4 Gs, Vt;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int jr = 4 * q4 + r;
+                            const int jj = (jr < NG) ? jr : 0;
+                            const float sq = (jr < NG) ? AT(gsq, k, jj) : 0.0f;
+                            const float vt = (jr < NG) ? AT(gvt, k, jj) : 0.0f;
+                            Gs[r] = (c < NU) ? M::G(a.mp, jj, c) * sq : 0.0f;
+                            Vt[r] = (c == NX) ? vt : 0.0f;
+                        }
+                        Rt = xty(Gs, Gs, Rt);
+                        St = xty(Gs, Vt, St);
+                    }
+                    f32x4 Kk, Acl;
+                    qp_ok = backward_stage<NU>(P, Aa, Ba, Bta, Qt, St, Rt, conv, lane, NX, Kk, Acl) && qp_ok;
+#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
+                    store_tile_t(Kt + (size_t)k * TILE, lane, Kk);
+                    store_tile_t(Ct + (size_t)k * TILE, lane, Acl);
+#else
+                    asm volatile("" ::"v"(Kk), "v"(Acl));
+#endif
                 }
-                f32x4 Kk;
-                qp_ok = backward_stage<NU>(P, Aa, Ba, Qt, St, Rt, conv, lane, NX, Kk) && qp_ok;
-                store_tile(Kt + (size_t)k * TILE, lane, Kk);
             }
             __threadfence_block();
-            __syncthreads();
+            wave_sync();
             STAMP(2);
             // -------------------------------------------------------- phase F: forward sweep
+            // dx~+ = Acl~ dx~ ,  du = K~ dx~ : one dependent MFMA group per stage; the two tiles
+            // of a stage are prefetched FWD_PF stages ahead (a stage is shorter than an L2 miss).
             float* oX = use_ipm ? dXp : dX;
             float* oU = use_ipm ? dUp : dU;
             f32x4 v;
@@ -279,80 +329,104 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * q4 + r;
                 float t = 0.0f;
-                if (c == 0 && row < NX) t = x0[row < NX ? row : 0] - Xs[row < NX ? row : 0];
+                if (c == 0 && row < NX) t = x0[row < NX ? row : 0] - AT(Xs, 0, row < NX ? row : 0);
                 if (c == 0 && row == NX) t = 1.0f;
                 v[r] = t;
             }
             if (c == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * q4 + r < NX) oX[4 * q4 + r] = v[r];
+                    if (4 * q4 + r < NX) AT(oX, 0, 4 * q4 + r) = v[r];
             }
-            for (int k = 0; k < N; ++k) {
-                const f32x4 du = forward_stage(v, At + (size_t)k * TILE, Bt + (size_t)k * TILE,
-                                               Kt + (size_t)k * TILE, lane);
-                if (c == 0) {
+            constexpr int FWD_PF = 4;
+            f32x4 Kr[FWD_PF], Cr[FWD_PF];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q4 + r;
-                        if (row < NU) oU[k * NU + row] = du[r];
-                        if (row < NX) oX[(k + 1) * NX + row] = v[r];
+            for (int j = 0; j < FWD_PF; ++j) {
+                const int kk = (j < N) ? j : N - 1;
+                Kr[j] = load_tile(Kt + (size_t)kk * TILE, lane);   // K~' of stage kk
+                Cr[j] = load_tile(Ct + (size_t)kk * TILE, lane);   // Acl~'
+            }
+            for (int k0 = 0; k0 < N; k0 += FWD_PF) {
+#pragma unroll
+                for (int j = 0; j < FWD_PF; ++j) {
+                    const int k = k0 + j;
+                    if (k >= N) break;
+                    const f32x4 Kc = Kr[j], Cc = Cr[j];
+                    const int kn = (k + FWD_PF < N) ? k + FWD_PF : N - 1;
+                    Kr[j] = load_tile(Kt + (size_t)kn * TILE, lane);
+                    Cr[j] = load_tile(Ct + (size_t)kn * TILE, lane);
+                    const f32x4 du = xty(Kc, v);
+                    v = xty(Cc, v);
+                    if (c == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 4 * q4 + r;
+                            if (row < NU) AT(oU, k, row) = du[r];
+                            if (row < NX) AT(oX, k + 1, row) = v[r];
+                        }
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
             STAMP(3);
             // -------------------------------------------------------- phase I: IPM update
             if (use_ipm) {
                 float ap_l = 1.0f, ad_l = 1.0f;
-                for (int k = lane; k < N; k += 64) {
+                float ds[(N_LANE_STAGES) * NG], dl[(N_LANE_STAGES) * NG];
+#pragma unroll
+                for (int ks = 0; ks < N_LANE_STAGES; ++ks) {
+                    const int k = lane + 64 * ks;
+                    if (k >= N) break;
                     float du[NU], g[NG];
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) du[i] = dUp[k * NU + i];
+                    for (int i = 0; i < NU; ++i) du[i] = AT(dUp, k, i);
                     M::gdot(a.mp, du, g);
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
-                        if (!((am >> j) & 1u)) continue;
-                        const float s = sv[k * NG + j], l = lv[k * NG + j], cj = cv[k * NG + j];
-                        const float ds = -(g[j] + cj) - s;
-                        const float dl = tau / s - l - l / s * ds;
-                        if (ds < 0.0f) ap_l = fminf(ap_l, -a.gamma * s / ds);
-                        if (dl < 0.0f) ad_l = fminf(ad_l, -a.gamma * l / dl);
+                        const bool on = (am >> j) & 1u;
+                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = AT(cv, k, j);
+                        const float is = fast_rcp(s);
+                        const float dsj = -(g[j] + cj) - s;
+                        const float dlj = tau * is - l - l * is * dsj;
+                        ds[ks * NG + j] = on ? dsj : 0.0f;
+                        dl[ks * NG + j] = on ? dlj : 0.0f;
+                        if (on && dsj < 0.0f) ap_l = fminf(ap_l, -a.gamma * s / dsj);
+                        if (on && dlj < 0.0f) ad_l = fminf(ad_l, -a.gamma * l / dlj);
                     }
                 }
                 const float ap = wave_min(ap_l), ad = wave_min(ad_l);
-                for (int k = lane; k < N; k += 64) {
-                    float du[NU], g[NG];
+                float m_l = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) du[i] = dUp[k * NU + i];
-                    M::gdot(a.mp, du, g);
+                for (int ks = 0; ks < N_LANE_STAGES; ++ks) {
+                    const int k = lane + 64 * ks;
+                    if (k >= N) break;
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
-                        if (!((am >> j) & 1u)) continue;
-                        const float s = sv[k * NG + j], l = lv[k * NG + j], cj = cv[k * NG + j];
-                        const float ds = -(g[j] + cj) - s;
-                        const float dl = tau / s - l - l / s * ds;
-                        sv[k * NG + j] = s + ap * ds;
-                        lv[k * NG + j] = l + ad * dl;
+                        const float s = AT(sv, k, j) + ap * ds[ks * NG + j];
+                        const float l = AT(lv, k, j) + ad * dl[ks * NG + j];
+                        AT(sv, k, j) = s;
+                        AT(lv, k, j) = l;
+                        if ((am >> j) & 1u) m_l += s * l;
                     }
                 }
-                for (int i = lane; i < (N + 1) * NX; i += 64) dX[i] += ap * (dXp[i] - dX[i]);
-                for (int i = lane; i < N * NU; i += 64) dU[i] += ap * (dUp[i] - dU[i]);
-                __syncthreads();
+                mu_sum = wave_sum(m_l);
+                for (int i = lane; i < NX * NS; i += 64) dX[i] += ap * (dXp[i] - dX[i]);
+                for (int i = lane; i < NU * NS; i += 64) dU[i] += ap * (dUp[i] - dU[i]);
+                wave_sync();
             }
         }
         STAMP(4);
         // ------------------------------------------------------------ phase S: step
         float sn_l = 0.0f;
         bool bad_l = false;
-        for (int i = lane; i < (N + 1) * NX; i += 64) {
+        for (int i = lane; i < NX * NS; i += 64) {
             const float v = dX[i];
             bad_l = bad_l || !(fabsf(v) <= 1e30f);
             sn_l = fmaxf(sn_l, fabsf(v));
         }
-        for (int i = lane; i < N * NU; i += 64) {
+        for (int i = lane; i < NU * NS; i += 64) {
             const float v = dU[i];
             bad_l = bad_l || !(fabsf(v) <= 1e30f);
             sn_l = fmaxf(sn_l, fabsf(v));
@@ -368,9 +442,9 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 for (int k = lane; k < N; k += 64) {
                     float x[NX], u[NU], xn[NX], p[NP > 0 ? NP : 1];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) x[i] = Xs[k * NX + i] + al * dX[k * NX + i];
+                    for (int i = 0; i < NX; ++i) x[i] = AT(Xs, k, i) + al * AT(dX, k, i);
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) u[i] = Us[k * NU + i] + al * dU[k * NU + i];
+                    for (int i = 0; i < NU; ++i) u[i] = AT(Us, k, i) + al * AT(dU, k, i);
 #pragma unroll
                     for (int i = 0; i < NP; ++i) p[i] = pg[(size_t)k * NP + i];
                     M::step(a.mp, x, u, p, xn);
@@ -380,7 +454,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                     for (int i = 0; i < NX; ++i) {
                         const float e = x[i] - yk[i];
                         cst += 0.5f * a.W[i] * e * e;
-                        viol += fabsf(xn[i] - (Xs[(k + 1) * NX + i] + al * dX[(k + 1) * NX + i]));
+                        viol += fabsf(xn[i] - (AT(Xs, k + 1, i) + al * AT(dX, k + 1, i)));
                     }
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
@@ -398,10 +472,10 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                     m_l += cst + a.rho * viol;
                 }
                 if (lane < NX) {
-                    const float xe = Xs[N * NX + lane] + al * dX[N * NX + lane];
+                    const float xe = AT(Xs, N, lane) + al * AT(dX, N, lane);
                     const float e = xe - yre[lane];
                     m_l += 0.5f * a.We[lane] * e * e;
-                    m_l += a.rho * fabsf(x0[lane] - (Xs[lane] + al * dX[lane]));
+                    m_l += a.rho * fabsf(x0[lane] - (AT(Xs, 0, lane) + al * AT(dX, 0, lane)));
                 }
                 return wave_sum(m_l);
             };
@@ -412,14 +486,14 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 alpha *= 0.5f;
             }
         }
-        for (int i = lane; i < (N + 1) * NX; i += 64) Xs[i] += alpha * dX[i];
-        for (int i = lane; i < N * NU; i += 64) Us[i] += alpha * dU[i];
-        __syncthreads();
+        for (int i = lane; i < NX * NS; i += 64) Xs[i] += alpha * dX[i];
+        for (int i = lane; i < NU * NS; i += 64) Us[i] += alpha * dU[i];
+        wave_sync();
         if (!qp_ok) { status = NMPC_STATUS_QP; ++it; break; }
         if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; ++it; break; }
     }
-    for (int i = lane; i < (N + 1) * NX; i += 64) Xg[i] = Xs[i];
-    for (int i = lane; i < N * NU; i += 64) Ug[i] = Us[i];
+    for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; Xg[e] = AT(Xs, k, e - k * NX); }
+    for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; Ug[e] = AT(Us, k, e - k * NU); }
     STAMP(5);
 #ifdef NMPC_STAMPS
     if (lane == 0 && a.dbg)
@@ -434,6 +508,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             a.stats[4 * b + 3] = (float)it;
         }
     }
+#undef AT
 }
 
 }  // namespace nmpc

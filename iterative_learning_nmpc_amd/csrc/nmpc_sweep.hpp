@@ -20,13 +20,14 @@ __device__ __forceinline__ f32x4 mask_rows(f32x4 v, int lane, int n) {
     return v;
 }
 
-// One backward stage.  P: P~ of stage k+1 (in/out: P~ of stage k).  Aa, Ba: A~_k, B~_k.
+// One backward stage.  P: P~ of stage k+1 (in/out: P~ of stage k).  Aa, Ba: A~_k, B~_k; Bt = B~_k'.
 // Qt, St, Rt: additive cost tiles (Q~, S~, R incl. barrier terms).  conv: 2*CTILE floats of LDS.
-// hx: index of the homogeneous coordinate (= nx).  Kout: K~_k in accumulator layout.
-// Returns false on a non-positive pivot.
+// hx: index of the homogeneous coordinate (= nx).  Outputs in accumulator layout:
+// Kout = K~_k, Aclout = A~_k + B~_k K~_k (closed loop).  Returns false on a non-positive pivot.
 template <int NU>
-__device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Qt, f32x4 St,
-                                               f32x4 Rt, float* conv, int lane, int hx, f32x4& Kout) {
+__device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Bt, f32x4 Qt,
+                                               f32x4 St, f32x4 Rt, float* conv, int lane, int hx,
+                                               f32x4& Kout, f32x4& Aclout) {
     const f32x4 PA = xty(P, Aa);
     const f32x4 PB = xty(P, Ba);
     // A~'(P~A~) and its bitwise transpose (P~A~)'A~ (same products, same k order): their mean is
@@ -40,52 +41,52 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     float* T1 = conv + CTILE;
     lds_store_acc(T0, lane, Huu);
     lds_store_acc(T1, lane, Hux);
-    __syncthreads();
+    wave_sync();
 
     // column layout: lane L -> column (L&15) of tile (L>>4): Huu | H~ux | I | unused
     const int t = lane >> 4, c = lane & 15;
     const float* src = ((t & 1) ? T1 : T0) + c * LDC;
     float col[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {
-        const float v = src[i];
-        col[i] = (t < 2) ? v : ((t == 2 && i == c) ? 1.0f : 0.0f);
+    for (int i4 = 0; i4 < (NU + 3) / 4; ++i4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * i4 + r;
+            if (i < NU) col[i] = (t < 2) ? v[r] : ((t == 2 && i == c) ? 1.0f : 0.0f);
+        }
     }
+#ifndef NMPC_EXP_NOELIM
     const bool ok = ldl_eliminate<NU>(col);
-    __syncthreads();
+#else
+    const bool ok = true;
+#endif
+    wave_sync();
     if (t == 1 || t == 2) {
         float* dst = ((t == 1) ? T1 : T0) + c * LDC;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) dst[i] = col[i];
+        for (int i4 = 0; i4 < (NU + 3) / 4; ++i4) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (4 * i4 + r < NU) ? col[(4 * i4 + r < NU) ? 4 * i4 + r : 0] : 0.0f;
+            *reinterpret_cast<f32x4*>(dst + 4 * i4) = v;
+        }
     }
-    __syncthreads();
+    wave_sync();
     const f32x4 Y = mask_rows(lds_load_acc(T1, lane), lane, NU);
     const f32x4 W = mask_rows(lds_load_acc(T0, lane), lane, NU);
-    __syncthreads();
+    wave_sync();
 
     const f32x4 nY = -Y;
     Kout = xty(W, nY);
     f32x4 Pn = xty(nY, Y, Hxx);
-    // the constant term of the cost-to-go (corner NX,NX) feeds nothing: keep it at zero
+    // the constant term of the cost-to-go (corner hx,hx) feeds nothing: keep it at zero
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (c == hx && 4 * (lane >> 4) + r == hx) Pn[r] = 0.0f;
     P = Pn;
+    Aclout = xty(Bt, Kout, Aa);   // (B~')' K~ + A~
     return ok;
-}
-
-// One forward stage: v = [dx_k; 1] in column 0.  Returns du tile (column 0 = du_k), updates v.
-__device__ __forceinline__ f32x4 forward_stage(f32x4& v, const float* __restrict__ At,
-                                               const float* __restrict__ Bt,
-                                               const float* __restrict__ Kt, int lane) {
-    const f32x4 Ktt = load_tile_t(Kt, lane);
-    const f32x4 Att = load_tile_t(At, lane);
-    const f32x4 Btt = load_tile_t(Bt, lane);
-    const f32x4 du = xty(Ktt, v);
-    f32x4 vn = xty(Att, v);
-    vn = xty(Btt, du, vn);
-    v = vn;
-    return du;
 }
 
 }  // namespace nmpc

@@ -67,6 +67,25 @@ __device__ __forceinline__ f32x4 load_tile_t(const float* __restrict__ t, int la
     return v;
 }
 
+// transposed image of an accumulator-layout tile: 4 dword stores (64 B runs), so that a later
+// load_tile() of the same memory yields the accumulator layout of the TRANSPOSE in one 16 B load
+__device__ __forceinline__ void store_tile_t(float* __restrict__ t, int lane, f32x4 v) {
+    const int q = lane >> 4, c = lane & 15;
+    t[(4 * q + 0) * TS + c] = v[0];
+    t[(4 * q + 1) * TS + c] = v[1];
+    t[(4 * q + 2) * TS + c] = v[2];
+    t[(4 * q + 3) * TS + c] = v[3];
+}
+
+// Ordering point between LDS accesses of different lanes of ONE wavefront.  A workgroup here is a
+// single wave and the LDS serves a wave's DS instructions in issue order, so no s_barrier and no
+// counter drain is needed -- only the compiler must not move DS accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- LDS conversion tiles (column stride LDC) ----------------------------------------------
 __device__ __forceinline__ void lds_store_acc(float* t, int lane, f32x4 v) {
     const int q = lane >> 4, c = lane & 15;

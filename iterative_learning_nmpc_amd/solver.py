@@ -165,12 +165,13 @@ class BatchedNmpcSolver:
         return dX, dU, status
 
     def debug_tile(self, b: int, k: int, which: int) -> np.ndarray:
-        """16x16 stage tile (row, col) of problem b: 0 A~, 1 B~, 2 K~ (test hook)."""
+        """16x16 stage tile (row, col) of problem b: 0 A~, 1 B~, 2 K~, 3 Acl~ (test hook)."""
         out = np.zeros(256, dtype=np.float32)
         _lib.check(self.lib.nmpc_debug_read_tile(self._h, b, k, which,
                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))),
                    self._h, "nmpc_debug_read_tile")
-        return out.reshape(16, 16).T.copy()   # stored column-major
+        img = out.reshape(16, 16)
+        return img.T.copy() if which < 2 else img.copy()   # A~,B~ column-major; K~,Acl~ transposed images
 
     @property
     def workspace_bytes(self) -> int:

@@ -9,7 +9,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "gpurun_out", "libnmpc_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNMPC_STAMPS",
+extra = [x for x in sys.argv[2:] if x.startswith("-D")]
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNMPC_STAMPS", *extra,
                 "-o", out, os.path.join(ROOT, "iterative_learning_nmpc_amd", "csrc", "nmpc_api.hip")], check=True)
 os.environ["NMPC_HIP_LIB"] = out
 sys.path.insert(0, ROOT)
@@ -33,8 +34,8 @@ for _ in range(3):
     s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"])
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().astype(np.float64)
-names = ["linearise", "barrier tau", "backward", "forward", "ipm update", "step+store"]
+names = ["linearise", "ipm upd+coef", "backward", "forward", "last ipm upd", "step+store"]
 tot = d[:, :6].sum(1).mean()
-print(f"B={B}: mean cycles per wave {tot:.0f}")
+print(f"B={B} {extra}: mean cycles per wave {tot:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {d[:, i].mean():10.0f} cycles  {100 * d[:, i].mean() / tot:5.1f} %")
