@@ -1,0 +1,208 @@
+"""Batched MPC controller: the host-side mirror of `LocomotionMPC` for B rollouts at once.
+
+Restates the control flow of mpc_controller/mpc.py on top of the batched HIP solver:
+    set_command                      mpc.py:197-202
+    compute_base_ref_vel_tracking    mpc.py:210-272   (vectorised over the batch, same quantisation)
+    optimize                         mpc.py:317-369   (contact flags -> references -> init -> solve)
+    set_convergence_on_first_iter    mpc.py:464-473   (15 SQP iterations on the first solve)
+    open_loop                        mpc.py:416-462   (simulator-free receding horizon: plant = plan)
+    _replan / _step bookkeeping      mpc.py:171-186
+The plant is the declared centroidal model; the reference's whole-body plant,
+MuJoCo and the torque layer are outside this path.  All rollouts of a batch share the
+gait clock (they are replanned at the same nodes), which is how the reference generates its perturbed
+rollouts from one nominal rollout (data_collection_*_perturbed.py:176-247).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .config import get_quadruped_config
+from .contact_planner import ContactPlanner
+from .profiling import print_timings, time_fn
+from .references import rpy_to_matrix
+from .solver import BatchedNmpcSolver
+from .workloads import FEET, HIP_OFFSETS, MODEL_CENTROIDAL, model_params
+
+N_SQP_FIRST = 15   # mpc.py:465
+
+
+def base_ref_vel_tracking_batch(q, v_des, w_des, ref_state, t_horizon, nom_height, height_offset=0.0):
+    """Vectorised `compute_base_ref_vel_tracking` (mpc.py:210-272) for q[B,>=4], v_des[B,3],
+    w_des[B,3], ref_state[B,12].  Same roundings: np.round(.,2) on position, builtin round(.,1) on yaw,
+    np.round(.,1) on the commanded velocity; same crossed-bounds clips."""
+    q, v_des, w_des = (np.asarray(a, dtype=np.float64) for a in (q, v_des, w_des))
+    B = q.shape[0]
+    ref = np.zeros((B, 12))
+    ref[:, :2] = np.round(q[:, :2], 2)
+    ref[:, 2] = nom_height + height_offset
+    ref[:, 3] = [round(float(y), 1) for y in q[:, 3]]
+    R = np.stack([rpy_to_matrix(s[3:6][::-1]) for s in ref_state])
+    v_glob = np.round(np.einsum("bij,bj->bi", R, v_des), 1)
+    ref[:, 6:9] = v_glob
+    ref[:, 9:12] = w_des[:, ::-1]
+    ref_e = ref.copy()
+    R_yaw = np.stack([rpy_to_matrix(w * t_horizon) for w in w_des])
+    ref_e[:, 6:9] = np.einsum("bij,bj->bi", R_yaw, ref[:, 6:9])
+    reach = v_glob[:, :2] * t_horizon
+    ref_e[:, :2] = np.clip(ref_state[:, :2] + reach, -ref[:, :2] + 1.2 * reach, ref[:, :2] + 1.2 * reach)
+    yaw_reach = w_des[:, 2] * t_horizon
+    yaw_ref = ref_state[:, 3]
+    ref_e[:, 3] = np.clip(yaw_ref + yaw_reach, -yaw_ref + 1.5 * yaw_reach, yaw_ref + 1.5 * yaw_reach)
+    ref[:, :2] += 0.75 * (ref_e[:, :2] - ref[:, :2])
+    ref[:, 3] += 0.75 * (ref_e[:, 3] - ref[:, 3])
+    ref_e[:, 8] = 0.0
+    ref_e[:, 4:6] = 0.0
+    ref[:, 4:6] = 0.0
+    ref_e[:, 10:12] = 0.0
+    return ref, ref_e
+
+
+class BatchedLocomotionMPC:
+    """B centroidal rollouts driven by one batched NMPC solve per replanning step."""
+
+    def __init__(self, batch: int, gait_name: str = "trot", robot_name: str = "go2", n_nodes: int = 50,
+                 device="cuda:0", sim_dt: float = 1.0e-3, height_offset: float = 0.0,
+                 compute_timings: bool = True, mass: float = 15.0, inertia=(0.11, 0.27, 0.33)):
+        self.batch = int(batch)
+        self.config_gait, self.config_opt, self.config_cost = get_quadruped_config(gait_name, robot_name)
+        self.n_nodes = int(n_nodes)
+        self.height_offset = height_offset
+        self.sim_dt = sim_dt
+        self.dt_nodes = self.config_opt.time_horizon / self.n_nodes
+        self.replanning_freq = self.config_opt.replanning_freq
+        self.replanning_steps = int(1 / (self.replanning_freq * sim_dt))                # mpc.py:113
+        self.nodes_per_replan = max(1, int(round(self.replanning_steps * sim_dt / self.dt_nodes)))
+        self.contact_planner = ContactPlanner(FEET, self.dt_nodes, self.config_gait)
+        self.compute_timings = compute_timings
+        self.timings = defaultdict(list)
+
+        self.mp = model_params(dt=self.dt_nodes, mass=mass, Ixx=inertia[0], Iyy=inertia[1], Izz=inertia[2])
+        self.solver = BatchedNmpcSolver(MODEL_CENTROIDAL, self.n_nodes, self.batch, device, compute_timings)
+        self.device = self.solver.device
+        self.solver.set_model_params(self.mp)
+        W = np.concatenate([self.config_cost.W_base, self.config_cost.W_cnt_f_reg.ravel()])
+        self.solver.set_cost_weights(W, self.config_cost.W_e_base, self.config_cost.reg_eps,
+                                     self.config_cost.reg_eps_e)
+        self.solver.set_max_qp_iter(self.config_opt.max_qp_iter)
+        self.reset()
+
+    # -- state ------------------------------------------------------------------------------------
+    def reset(self) -> None:
+        B, N = self.batch, self.n_nodes
+        self.first_solve = True
+        self.sim_step = 0
+        self.current_opt_node = 0
+        self.v_des = np.zeros((B, 3))
+        self.w_des = np.zeros((B, 3))
+        self.base_ref_vel_tracking = np.zeros((B, 12))
+        self.foot_pos = None
+        self.X = torch.zeros(B, N + 1, 12, dtype=torch.float32, device=self.device)
+        self.U = torch.zeros(B, N, 12, dtype=torch.float32, device=self.device)
+        self.status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.stats = torch.zeros(B, 4, dtype=torch.float32, device=self.device)
+        self.timings = defaultdict(list)
+        self.solver.last_node = 0
+
+    def set_command(self, v_des=np.zeros(3), w_yaw=0.0) -> None:
+        self.v_des = np.broadcast_to(np.asarray(v_des, dtype=np.float64), (self.batch, 3)).copy()
+        self.w_des[:, 2] = w_yaw
+
+    def set_convergence_on_first_iter(self) -> None:
+        if self.first_solve:
+            self.solver.set_max_iter(N_SQP_FIRST)
+            self.solver.set_nlp_tol(self.config_opt.nlp_tol / 10.0)
+        elif self.sim_step <= self.replanning_steps:
+            self.solver.set_max_iter(self.config_opt.max_iter)
+            self.solver.set_nlp_tol(self.config_opt.nlp_tol)
+
+    def _replan(self) -> bool:
+        return self.sim_step % self.replanning_steps == 0
+
+    def compute_base_ref_vel_tracking(self, q: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        return base_ref_vel_tracking_batch(q, self.v_des, self.w_des, self.base_ref_vel_tracking,
+                                           self.config_opt.time_horizon, self.config_gait.nom_height,
+                                           self.height_offset)
+
+    def increment_base_ref_position(self, n_steps: int = 1) -> None:
+        for b in range(self.batch):
+            R = rpy_to_matrix(self.base_ref_vel_tracking[b, 3:6][::-1])
+            v_glob = np.round(R @ self.v_des[b], 1)
+            self.base_ref_vel_tracking[b, :2] += v_glob[:2] * self.sim_dt * n_steps
+            self.base_ref_vel_tracking[b, 3] += self.w_des[b, 2] * self.sim_dt * n_steps
+
+    # -- one replanning step --------------------------------------------------------------------
+    def build_problem(self, x: np.ndarray):
+        """Per-stage references and parameters for the current node (host side, as mpc.py:332-366)."""
+        B, N = self.batch, self.n_nodes
+        contacts = self.contact_planner.get_contacts(self.current_opt_node, N + 1).astype(np.float64)  # [4,N+1]
+        base_ref, base_ref_e = self.compute_base_ref_vel_tracking(x)
+        if self.foot_pos is None:   # feet under the hips at the first call (setup_initial_feet_pos, solver.py:194)
+            self.foot_pos = x[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]
+        params = np.zeros((B, N + 1, 16))
+        params[:, :, :4] = contacts.T[None]
+        params[:, :, 4:] = self.foot_pos.reshape(B, 1, 12)
+        n_stance = np.maximum(contacts[:, :N].sum(0), 1.0)
+        yref = np.zeros((B, N, 24))
+        yref[:, :, :12] = base_ref[:, None, :]
+        yref[:, :, 14::3] = (contacts[:, :N].T * (-self.mp[5] * self.mp[1] / n_stance)[:, None])[None]
+        return yref, base_ref_e, params
+
+    @time_fn("optimize")
+    def optimize(self, x: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One batched replanning solve from the states x[B,12]; returns device X[B,N+1,12], U[B,N,12]."""
+        s = self.solver
+        yref, yref_e, params = self.build_problem(x)
+        if self.first_solve:
+            self.X[:] = s.to_device(np.repeat(x[:, None, :], self.n_nodes + 1, axis=1))
+            self.U[:] = s.to_device(yref[:, :, 12:])
+        elif self.config_opt.warm_start_sol:
+            s.warm_start_solver(self.X, self.U, self.current_opt_node - s.last_node)
+        s.last_node = self.current_opt_node
+        s.solve(s.to_device(x), s.to_device(yref), s.to_device(yref_e), s.to_device(params),
+                self.X, self.U, self.status, self.stats)
+        return self.X, self.U
+
+    # -- simulator-free rollout -------------------------------------------------------------------
+    def open_loop(self, x0: np.ndarray, trajectory_time: float, push: Optional[dict] = None):
+        """Receding-horizon rollout where the plant follows the plan (mpc.py:416-462).
+
+        Returns (S[B,K,19] float32 device, t[K]): one recorded state per replanning step, in the
+        slot order of the reference's recorded state (DAgger/utils/RolloutMPC.py:221):
+            [phase, v(6) = rdot, body rates, q[2:] = z, yaw, pitch, roll, base_wrt_feet(8)].
+        push = {"start": s, "duration": s, "force": [B,3] N}: a base push applied to the plant as the
+        velocity impulse F dt / m per replanning interval (the reference pushes the MuJoCo base,
+        data_collection_force_perturbation.py:213-248).
+        """
+        x = np.array(x0, dtype=np.float64)
+        n_replans = int(np.floor(trajectory_time / (self.replanning_steps * self.sim_dt) + 1e-9))
+        dt_replan = self.replanning_steps * self.sim_dt
+        rec, times = [], []
+        for i in range(n_replans):
+            t_now = i * dt_replan
+            self.set_convergence_on_first_iter()
+            X, _ = self.optimize(x)
+            self.first_solve = False
+            rec.append(self.record_state(x, t_now))
+            times.append(t_now)
+            x = X[:, self.nodes_per_replan, :].double().cpu().numpy()          # plant = plan
+            if push is not None and push["start"] <= t_now < push["start"] + push["duration"]:
+                x[:, 6:9] += np.asarray(push["force"]) * dt_replan / self.mp[1]
+            self.sim_step += self.replanning_steps
+            self.current_opt_node += self.nodes_per_replan
+            self.increment_base_ref_position(self.replanning_steps)
+        S = torch.as_tensor(np.stack(rec, axis=1), dtype=torch.float32).to(self.device).contiguous()
+        return S, np.asarray(times)
+
+    def record_state(self, x: np.ndarray, t: float) -> np.ndarray:
+        period = self.config_gait.nominal_period
+        phase = np.round((t % period) / period, 4)
+        base_wrt_feet = (x[:, None, :2] - self.foot_pos[:, :, :2]).reshape(self.batch, 8)
+        return np.concatenate([np.full((self.batch, 1), phase), x[:, 6:9], x[:, 9:12], x[:, 2:6],
+                               base_wrt_feet], axis=1)
+
+    def print_timings(self) -> None:
+        print_timings(self.timings)

@@ -234,3 +234,54 @@ def test_tracking_error_golden_ood_selection(dev, golden_dir):
     sel = (wgt.cpu().numpy() == 5.0) & matched
     margin = np.abs(err.cpu().numpy() - 4.0) > 1e-4                    # ignore fp32 ties at the threshold
     assert np.array_equal(sel[margin], g["ood_selected"][margin])
+
+
+# ------------------------------------------------------------------------------- controller / rollouts
+def test_open_loop_rollouts_match_oracle_driven_loop(dev, oracle64):
+    """`BatchedLocomotionMPC.open_loop` (mirror of mpc.py:416-462) against the same host loop
+    driven by the CPU oracle: 8 replans (first one 15 SQP iterations), nominal + pushed rollouts."""
+    from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC, N_SQP_FIRST
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    B, T = 6, 0.32
+    rng = np.random.default_rng(7)
+    x0 = np.zeros((B, 12)); x0[:, 2] = 0.3
+    force = np.zeros((B, 3)); force[1:] = rng.uniform(-1, 1, (B - 1, 3)) * 60.0     # rollout 0 = nominal
+    push = dict(start=0.08, duration=0.12, force=force)
+
+    mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+    mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    S, t = mpc.open_loop(x0, T, push)
+    torch.cuda.synchronize()
+    assert S.shape == (B, 8, 19) and len(t) == 8 and mpc.current_opt_node == 16
+    assert (mpc.status.cpu().numpy() != 1).all() and np.isfinite(S.cpu().numpy()).all()
+
+    # the same loop with the oracle as the solver
+    ref = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+    ref.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    x, X, U, rec = x0.copy(), None, None, []
+    for i in range(8):
+        yref, yref_e, params = ref.build_problem(x)
+        first = X is None
+        if first:
+            X, U = np.repeat(x[:, None, :], 51, axis=1), yref[:, :, 12:].copy()
+        else:
+            X, U = oracle64.shift_warm_start(X, U, ref.nodes_per_replan)
+        opt = oracle64.opt(max_sqp_iter=N_SQP_FIRST if first else 1, n_ipm=6, yref_per_stage=1,
+                           nlp_tol=(0.01 if first else 0.1), reg=ref.config_cost.reg_eps, reg_e=ref.config_cost.reg_eps_e)
+        W = np.concatenate([ref.config_cost.W_base, ref.config_cost.W_cnt_f_reg.ravel()])
+        X, U, _, _ = oracle64.solve_batch(1, 50, ref.mp, opt, W, ref.config_cost.W_e_base, x, yref, yref_e, params, X, U)
+        rec.append(ref.record_state(x, i * 0.04))
+        x = X[:, ref.nodes_per_replan].copy()
+        if push["start"] <= i * 0.04 < push["start"] + push["duration"]:
+            x[:, 6:9] += force * 0.04 / ref.mp[1]
+        ref.sim_step += ref.replanning_steps
+        ref.current_opt_node += ref.nodes_per_replan
+        ref.increment_base_ref_position(ref.replanning_steps)
+    S_ref = np.stack(rec, axis=1)
+    assert rel(S.cpu().numpy(), S_ref) < 1e-4, rel(S.cpu().numpy(), S_ref)
+
+    # tracking error of every rollout against the nominal one (rollout 0)
+    err, w = tracking_error(S, S[0].contiguous())
+    err = err.cpu().numpy()
+    assert np.all(err[0] == 0) and err[1:, -1].min() > 1e-3
+    assert np.allclose(err, oracle64.tracking_error(S.cpu().numpy(), S[0].cpu().numpy()), rtol=1e-5, atol=1e-6)
