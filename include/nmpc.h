@@ -131,8 +131,9 @@ int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, cons
  * out_host: float[256].  Synchronises the device. */
 int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
 
-/* Diagnostic builds (-DNMPC_STAMPS) write per-phase cycle counts to dev float[B_max][8]
- * (linearise, barrier parameter, backward, forward, IPM update, step+write-back, -, -).
+/* Diagnostic builds (-DNMPC_STAMPS) write cycle counts to dev float[B_max][16]: 8 phases
+ * (linearise, IPM update+coefficients, backward, forward, last IPM update, step+write-back, -, -)
+ * and 8 segments of the backward stage (tools/phase_shares.py).
  * Production builds ignore the buffer.  NULL detaches it. */
 int nmpc_debug_set_buffer(void *handle, float *dev_buffer);
 

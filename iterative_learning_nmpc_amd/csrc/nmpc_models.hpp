@@ -54,6 +54,8 @@ struct DoubleIntegrator {
     __device__ static void gdot(const ModelParams&, const float (&v)[NU], float (&o)[NG]) {
         o[0] = v[0]; o[1] = -v[0]; o[2] = v[1]; o[3] = -v[1];
     }
+    // inputs that couple with others in Huu (all of them here)
+    __device__ static unsigned input_mask(const ModelParams&, const float*) { return 0x3u; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -81,9 +83,9 @@ struct Centroidal {
     };
     __device__ static void core(const ModelParams& mp, const float (&x)[NX], const float (&u)[NU],
                                 const float* p, Core& k) {
-        __sincosf(x[3], &k.t.sz, &k.t.cz);
-        __sincosf(x[4], &k.t.sy, &k.t.cy);
-        __sincosf(x[5], &k.t.sx, &k.t.cx);
+        sincosf(x[3], &k.t.sz, &k.t.cz);
+        sincosf(x[4], &k.t.sy, &k.t.cy);
+        sincosf(x[5], &k.t.sx, &k.t.cx);
         rot(k.t, k.R);
         k.w[0] = x[11]; k.w[1] = x[10]; k.w[2] = x[9];
         k.F[0] = k.F[1] = k.F[2] = 0.f;
@@ -262,6 +264,14 @@ struct Centroidal {
         unsigned m = 0;
 #pragma unroll
         for (int f = 0; f < 4; ++f) m |= (p[f] > 0.5f) ? (0xFu << (4 * f)) : 0u;
+        return m;
+    }
+    // inputs that couple with others in Huu: the forces of stance feet.  A swing foot's force has a
+    // zero column in B and no active constraint row, so its Huu row/column is exactly diagonal.
+    __device__ static unsigned input_mask(const ModelParams&, const float* p) {
+        unsigned m = 0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) m |= (p[f] > 0.5f) ? (0x7u << (3 * f)) : 0u;
         return m;
     }
     __device__ static void gdot(const ModelParams& mp, const float (&v)[NU], float (&o)[NG]) {

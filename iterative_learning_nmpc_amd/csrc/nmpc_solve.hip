@@ -11,6 +11,8 @@
 // trajectories, gradients and IPM state of the problem live in LDS (~32 KB at N=50).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/nmpc.h"
 #include "nmpc_models.hpp"
 #include "nmpc_sweep.hpp"
@@ -45,11 +47,16 @@ constexpr int N_LANE_STAGES = 2;   // lane = stage phases keep per-stage data in
 // Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
 // a buffer of their own; the production kernel contains no stamp.
 #ifdef NMPC_STAMPS
-#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    StageStamps sst = {0, {0, 0, 0, 0, 0, 0, 0, 0}}
+#define SST_PASS , sst
+#define SST_TILES(i) SST(i)
 #define STAMP(i) do { const unsigned long long st_t1 = __builtin_readcyclecounter(); st_acc[i] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define SST_PASS
+#define SST_TILES(i)
 #endif
 
 // LDS layout of one problem.  Every per-stage array is FEATURE-major, [feature][stage] with an odd
@@ -58,7 +65,7 @@ constexpr int N_LANE_STAGES = 2;   // lane = stage phases keep per-stage data in
 template <class M>
 struct Lds {
     int NS;   // stage stride (odd, >= N+1)
-    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, cv, gsq, gvt, act, conv, total;   // float offsets
+    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, cv, gsq, gvt, act, umk, conv, total;   // float offsets
     __host__ __device__ explicit Lds(int N) {
         NS = (N + 1) | 1;
         int o = 0;
@@ -76,7 +83,8 @@ struct Lds {
         gsq = o; o += round4(M::NG * NS);
         gvt = o; o += round4(M::NG * NS);
         act = o; o += round4(NS);
-        conv = o; o += 2 * CTILE;
+        umk = o; o += round4(NS);
+        conv = o; o += 3 * CTILE;
         total = o;
     }
 };
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     float* sv = smem + L.sv;   float* lv = smem + L.lv;   float* cv = smem + L.cv;
     float* gsq = smem + L.gsq; float* gvt = smem + L.gvt;
     unsigned* actm = reinterpret_cast<unsigned*>(smem + L.act);
+    unsigned* umask = reinterpret_cast<unsigned*>(smem + L.umk);
     float* conv = smem + L.conv;
 #define AT(arr, k, i) (arr)[(i) * NS + (k)]
 
@@ -130,6 +139,28 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     const float wq_c = (c < NX) ? a.W[c] + a.reg : 0.0f;
     const float wr_c = (c < NU) ? a.W[NX + (c < NU ? c : 0)] + a.reg : 0.0f;
     const float we_c = (c < NX) ? a.We[c < NX ? c : 0] + a.reg_e : 0.0f;
+    // per-lane constants of the stage sweeps: which element of q / r / sqrt(D) / v each of the
+    // lane's four tile registers takes (a clamped LDS feature index and a 0/1 mask), so that the
+    // cost tiles of a stage are built with unconditional loads and selects (no branches)
+    SweepLane sl;
+    sl.init(conv, lane, NX);
+    f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
+    int qf[4], rf[4], gf[4];     // feature indices
+    bool qm[4], rm[4], gm[4];    // masks
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q4 + r;
+        Qc[r] = (row == c && row < NX) ? wq_c : 0.0f;
+        Rc[r] = (row == c && row < NU) ? wr_c : 0.0f;
+        qm[r] = (c == NX && row < NX) || (row == NX && c < NX);
+        qf[r] = (c == NX) ? (row < NX ? row : 0) : (c < NX ? c : 0);
+        rm[r] = (c == NX && row < NU);
+        rf[r] = (row < NU) ? row : 0;
+        gm[r] = row < NG;
+        gf[r] = (row < NG) ? row : 0;
+        Gc[r] = (row < NG && c < NU) ? M::G(a.mp, gf[r], c) : 0.0f;
+    }
+    const bool is_hx_col = (c == NX);
     wave_sync();
 
     int status = NMPC_STATUS_MAXITER;
@@ -184,6 +215,7 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 AT(rv, k, i) = a.W[NX + i] * e;
                 cost_l += 0.5f * a.W[NX + i] * e * e;
             }
+            umask[k] = M::input_mask(a.mp, p);
             if (a.n_ipm > 0) {
                 const unsigned am = M::active_mask(a.mp, p);
                 actm[k] = am;
@@ -261,61 +293,58 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             // B = 1024, so nothing else hides the L2 / Infinity-Cache latency; and because vmcnt
             // retires in issue order, a distance of two keeps each stage's K~/Acl~ stores
             // younger than the loads the next stage waits for (no stall on store completion).
-            f32x4 Ar[2], Br[2], Tr[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kk = (N - 1 - j > 0) ? N - 1 - j : 0;
-                Ar[j] = load_tile(At + (size_t)kk * TILE, lane);
-                Br[j] = load_tile(Bt + (size_t)kk * TILE, lane);
-                Tr[j] = load_tile_t(Bt + (size_t)kk * TILE, lane);
-            }
-            for (int k0 = N - 1; k0 >= 0; k0 -= 2) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = k0 - j;
-                    if (k < 0) break;
-                    const f32x4 Aa = Ar[j], Ba = Br[j], Bta = Tr[j];
+            auto sweep = [&](auto ipm_tag) {
+                constexpr bool IPM = decltype(ipm_tag)::value;
+                const int k1 = (N - 2 > 0) ? N - 2 : 0;
+                f32x4 A0 = load_tile(At + (size_t)(N - 1) * TILE, lane);
+                f32x4 B0 = load_tile(Bt + (size_t)(N - 1) * TILE, lane);
+                f32x4 T0 = load_tile_t(Bt + (size_t)(N - 1) * TILE, lane);
+                f32x4 A1 = load_tile(At + (size_t)k1 * TILE, lane);
+                f32x4 B1 = load_tile(Bt + (size_t)k1 * TILE, lane);
+                f32x4 T1 = load_tile_t(Bt + (size_t)k1 * TILE, lane);
+                for (int k = N - 1; k >= 0; --k) {
+#ifdef NMPC_STAMPS
+                    sst.t0 = __builtin_readcyclecounter();
+#endif
                     const int kn = (k - 2 > 0) ? k - 2 : 0;
-                    Ar[j] = load_tile(At + (size_t)kn * TILE, lane);
-                    Br[j] = load_tile(Bt + (size_t)kn * TILE, lane);
-                    Tr[j] = load_tile_t(Bt + (size_t)kn * TILE, lane);
-                    f32x4 Qt, St, Rt;
-                    const float qc = (c < NX) ? AT(qv, k, c < NX ? c : 0) : 0.0f;
+                    const f32x4 A2 = load_tile(At + (size_t)kn * TILE, lane);
+                    const f32x4 B2 = load_tile(Bt + (size_t)kn * TILE, lane);
+                    const f32x4 T2 = load_tile_t(Bt + (size_t)kn * TILE, lane);
+                    f32x4 Qt, St, Rt = Rc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q4 + r;
-                        float vq = 0.0f;
-                        if (row == c && row < NX) vq = wq_c;
-                        if (c == NX && row < NX) vq = AT(qv, k, row < NX ? row : 0);
-                        if (row == NX && c < NX) vq = qc;
-                        Qt[r] = vq;
-                        St[r] = (c == NX && row < NU) ? AT(rv, k, row < NU ? row : 0) : 0.0f;
-                        Rt[r] = (row == c && row < NU) ? wr_c : 0.0f;
+                        const float qe = AT(qv, k, qf[r]);
+                        const float re = AT(rv, k, rf[r]);
+                        Qt[r] = Qc[r] + (qm[r] ? qe : 0.0f);
+                        St[r] = rm[r] ? re : 0.0f;
                     }
-                    if (use_ipm) {
+                    if constexpr (IPM) {
                         f32x4 Gs, Vt;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int jr = 4 * q4 + r;
-                            const int jj = (jr < NG) ? jr : 0;
-                            const float sq = (jr < NG) ? AT(gsq, k, jj) : 0.0f;
-                            const float vt = (jr < NG) ? AT(gvt, k, jj) : 0.0f;
-                            Gs[r] = (c < NU) ? M::G(a.mp, jj, c) * sq : 0.0f;
-                            Vt[r] = (c == NX) ? vt : 0.0f;
+                            const float sq = AT(gsq, k, gf[r]);
+                            const float vt = AT(gvt, k, gf[r]);
+                            Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
+                            Vt[r] = (gm[r] && is_hx_col) ? vt : 0.0f;
                         }
                         Rt = xty(Gs, Gs, Rt);
                         St = xty(Gs, Vt, St);
                     }
                     f32x4 Kk, Acl;
-                    qp_ok = backward_stage<NU>(P, Aa, Ba, Bta, Qt, St, Rt, conv, lane, NX, Kk, Acl) && qp_ok;
+                    SST_TILES(6);
+                    qp_ok = backward_stage<NU>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane, umask[k], Kk, Acl SST_PASS) && qp_ok;
 #ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
                     store_tile_t(Kt + (size_t)k * TILE, lane, Kk);
                     store_tile_t(Ct + (size_t)k * TILE, lane, Acl);
 #else
                     asm volatile("" ::"v"(Kk), "v"(Acl));
 #endif
+                    A0 = A1; B0 = B1; T0 = T1;
+                    A1 = A2; B1 = B2; T1 = T2;
+                    SST_TILES(5);
                 }
-            }
+            };
+            if (use_ipm) sweep(std::true_type{}); else sweep(std::false_type{});
             __threadfence_block();
             wave_sync();
             STAMP(2);
@@ -496,8 +525,10 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; Ug[e] = AT(Us, k, e - k * NU); }
     STAMP(5);
 #ifdef NMPC_STAMPS
-    if (lane == 0 && a.dbg)
-        for (int i = 0; i < 8; ++i) a.dbg[8 * b + i] = (float)st_acc[i];
+    if (lane == 0 && a.dbg) {
+        for (int i = 0; i < 8; ++i) a.dbg[16 * b + i] = (float)st_acc[i];
+        for (int i = 0; i < 8; ++i) a.dbg[16 * b + 8 + i] = (float)sst.acc[i];
+    }
 #endif
     if (lane == 0) {
         if (a.status) a.status[b] = status;

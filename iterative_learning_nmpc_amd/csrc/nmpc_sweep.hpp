@@ -20,72 +20,106 @@ __device__ __forceinline__ f32x4 mask_rows(f32x4 v, int lane, int n) {
     return v;
 }
 
+// Diagnostic builds (-DNMPC_STAMPS): cycle counters of the segments of one backward stage.
+#ifdef NMPC_STAMPS
+struct StageStamps { unsigned long long t0; unsigned long long acc[8]; };
+#define SST_ARG , StageStamps& sst
+#define SST_BEGIN sst.t0 = __builtin_readcyclecounter()
+#define SST(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); \
+                    sst.acc[i] += t1_ - sst.t0; sst.t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SST_ARG
+#define SST_BEGIN
+#define SST(i)
+#endif
+
+// Per-lane constants of the stage sweeps (computed once per kernel).
+struct SweepLane {
+    float* wb;        // write-back column of the eliminated system (groups 0/3 write to a dummy tile)
+    const float* rd;  // column this lane eliminates (Huu | H~ux), dummy for groups 2/3
+    bool from_lds;    // group < 2: column comes from the conversion tiles
+    int ident_row;    // group 2: row of the 1 in the identity right-hand side, else -1
+    bool corner[4];   // true at the (hx,hx) corner of a tile
+    __device__ __forceinline__ void init(float* conv, int lane, int hx) {
+        const int t = lane >> 4, c = lane & 15;
+        float* T0 = conv;
+        float* T1 = conv + CTILE;
+        float* Td = conv + 2 * CTILE;
+        wb = ((t == 1) ? T1 : (t == 2) ? T0 : Td) + c * LDC;
+        rd = ((t == 0) ? T0 : (t == 1) ? T1 : Td) + c * LDC;
+        from_lds = t < 2;
+        ident_row = (t == 2) ? c : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) corner[r] = (c == hx && 4 * t + r == hx);
+    }
+};
+
 // One backward stage.  P: P~ of stage k+1 (in/out: P~ of stage k).  Aa, Ba: A~_k, B~_k; Bt = B~_k'.
-// Qt, St, Rt: additive cost tiles (Q~, S~, R incl. barrier terms).  conv: 2*CTILE floats of LDS.
-// hx: index of the homogeneous coordinate (= nx).  Outputs in accumulator layout:
-// Kout = K~_k, Aclout = A~_k + B~_k K~_k (closed loop).  Returns false on a non-positive pivot.
+// Qt, St, Rt: additive cost tiles (Q~, S~, R incl. barrier terms).  conv: 3*CTILE floats of LDS.
+// coupled: inputs whose pivots need an update loop (see ldl_eliminate).  Outputs in accumulator
+// layout: Kout = K~_k, Aclout = A~_k + B~_k K~_k.  Returns false on a non-positive pivot.
+// Straight-line code (no branches besides the pivot skips) so the scheduler can overlap the
+// MFMAs that are off the critical path (symmetrisation, closed loop) with the elimination.
 template <int NU>
 __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Bt, f32x4 Qt,
-                                               f32x4 St, f32x4 Rt, float* conv, int lane, int hx,
-                                               f32x4& Kout, f32x4& Aclout) {
+                                               f32x4 St, f32x4 Rt, float* conv, const SweepLane& sl,
+                                               int lane, unsigned coupled, f32x4& Kout, f32x4& Aclout SST_ARG) {
+    SST_BEGIN;
     const f32x4 PA = xty(P, Aa);
     const f32x4 PB = xty(P, Ba);
     // A~'(P~A~) and its bitwise transpose (P~A~)'A~ (same products, same k order): their mean is
     // exactly symmetric, which keeps P~ symmetric over the whole recursion (the tile algebra
     // uses P~ as its own transpose).
-    const f32x4 Hxx = 0.5f * (xty(Aa, PA, Qt) + xty(PA, Aa, Qt));
     const f32x4 Hux = xty(Ba, PA, St);
     const f32x4 Huu = xty(Ba, PB, Rt);
+    const f32x4 Hxx = 0.5f * (xty(Aa, PA, Qt) + xty(PA, Aa, Qt));
 
-    float* T0 = conv;
-    float* T1 = conv + CTILE;
-    lds_store_acc(T0, lane, Huu);
-    lds_store_acc(T1, lane, Hux);
+    SST(0);
+    lds_store_acc(conv, lane, Huu);
+    lds_store_acc(conv + CTILE, lane, Hux);
     wave_sync();
 
     // column layout: lane L -> column (L&15) of tile (L>>4): Huu | H~ux | I | unused
-    const int t = lane >> 4, c = lane & 15;
-    const float* src = ((t & 1) ? T1 : T0) + c * LDC;
     float col[NU];
 #pragma unroll
     for (int i4 = 0; i4 < (NU + 3) / 4; ++i4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sl.rd + 4 * i4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * i4 + r;
-            if (i < NU) col[i] = (t < 2) ? v[r] : ((t == 2 && i == c) ? 1.0f : 0.0f);
+            if (i < NU) col[i] = sl.from_lds ? v[r] : ((i == sl.ident_row) ? 1.0f : 0.0f);
         }
     }
+    SST(1);
 #ifndef NMPC_EXP_NOELIM
-    const bool ok = ldl_eliminate<NU>(col);
+    const bool ok = ldl_eliminate<NU>(col, coupled);
 #else
     const bool ok = true;
 #endif
+    SST(2);
     wave_sync();
-    if (t == 1 || t == 2) {
-        float* dst = ((t == 1) ? T1 : T0) + c * LDC;
 #pragma unroll
-        for (int i4 = 0; i4 < (NU + 3) / 4; ++i4) {
-            f32x4 v;
+    for (int i4 = 0; i4 < (NU + 3) / 4; ++i4) {
+        f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (4 * i4 + r < NU) ? col[(4 * i4 + r < NU) ? 4 * i4 + r : 0] : 0.0f;
-            *reinterpret_cast<f32x4*>(dst + 4 * i4) = v;
-        }
+        for (int r = 0; r < 4; ++r) v[r] = (4 * i4 + r < NU) ? col[(4 * i4 + r < NU) ? 4 * i4 + r : 0] : 0.0f;
+        *reinterpret_cast<f32x4*>(sl.wb + 4 * i4) = v;
     }
     wave_sync();
-    const f32x4 Y = mask_rows(lds_load_acc(T1, lane), lane, NU);
-    const f32x4 W = mask_rows(lds_load_acc(T0, lane), lane, NU);
+    const f32x4 Y = mask_rows(lds_load_acc(conv + CTILE, lane), lane, NU);
+    const f32x4 W = mask_rows(lds_load_acc(conv, lane), lane, NU);
     wave_sync();
 
+    SST(3);
     const f32x4 nY = -Y;
-    Kout = xty(W, nY);
     f32x4 Pn = xty(nY, Y, Hxx);
+    Kout = xty(W, nY);
     // the constant term of the cost-to-go (corner hx,hx) feeds nothing: keep it at zero
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (c == hx && 4 * (lane >> 4) + r == hx) Pn[r] = 0.0f;
+    for (int r = 0; r < 4; ++r) Pn[r] = sl.corner[r] ? 0.0f : Pn[r];
     P = Pn;
     Aclout = xty(Bt, Kout, Aa);   // (B~')' K~ + A~
+    SST(4);
     return ok;
 }
 

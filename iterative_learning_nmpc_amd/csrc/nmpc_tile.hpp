@@ -103,19 +103,24 @@ __device__ __forceinline__ f32x4 lds_load_acc(const float* t, int lane) {
 // so that  Huu^-1 = W'W,  K = -W'Y,  P+ = Hxx - Y'Y  need no back substitution.
 // All cross-lane traffic is v_readlane of lane j's registers (wave-uniform scalars).
 // Returns false if a pivot is not positive (status "QP failure").
+// `coupled`: bit j set if input j may couple with other inputs.  A pivot whose column is exactly
+// diagonal (a masked-out input: zero column of B, no active constraint row) has all multipliers
+// equal to zero, so its update loop is skipped -- bit-identical result, wave-uniform branch.
 template <int NU>
-__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU]) {
+__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled = 0xFFFFFFFFu) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const float d = bcast(col[j], j);
         ok = ok && (d > 0.0f);
-        const float rinv = fast_rcp(d);
-        const float w = col[j] * rinv;
+        if ((coupled >> j) & 1u) {
+            const float rinv = fast_rcp(d);
+            const float w = col[j] * rinv;
+            float l[NU];
 #pragma unroll
-        for (int i = j + 1; i < NU; ++i) {
-            const float l = bcast(col[i], j);
-            col[i] = fmaf(-l, w, col[i]);
+            for (int i = j + 1; i < NU; ++i) l[i] = bcast(col[i], j);
+#pragma unroll
+            for (int i = j + 1; i < NU; ++i) col[i] = fmaf(-l[i], w, col[i]);
         }
         col[j] = col[j] * __builtin_amdgcn_rsqf(d);
     }

@@ -27,7 +27,7 @@ w = wl.centroidal_trot(B=B, N=50, seed=0)
 s = BatchedNmpcSolver(w.model_id, w.N, B, "cuda:0")
 s.set_model_params(w.mp)
 s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
-dbg = torch.zeros(B, 8, device="cuda:0")
+dbg = torch.zeros(B, 16, device="cuda:0")
 s.lib.nmpc_debug_set_buffer(s._h, ctypes.c_void_p(dbg.data_ptr()))
 t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
 for _ in range(3):
@@ -39,3 +39,8 @@ tot = d[:, :6].sum(1).mean()
 print(f"B={B} {extra}: mean cycles per wave {tot:.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {d[:, i].mean():10.0f} cycles  {100 * d[:, i].mean() / tot:5.1f} %")
+seg = ["products PA..Hxx", "LDS -> columns", "LDL' elimination", "columns -> LDS -> acc", "K, P+, Acl", "stores + loop", "cost tiles (+IPM MFMA)"]
+n_stage = 6 * 50
+print("backward stage segments (cycles per stage; stamps serialise, read shares):")
+for i, n in enumerate(seg):
+    print(f"  {n:24s} {d[:, 8 + i].mean() / n_stage:8.0f}")
