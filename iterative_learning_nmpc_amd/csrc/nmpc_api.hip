@@ -92,7 +92,7 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) {
-        h->ws_bytes = (size_t)dims->B_max * nmpc::WS_TILES * dims->N * nmpc::TILE * sizeof(float);
+        h->ws_bytes = (size_t)dims->B_max * nmpc::ws_tiles(dims->N) * nmpc::TILE * sizeof(float);
         e = hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes);
     }
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
@@ -269,12 +269,13 @@ int nmpc_debug_set_buffer(void* handle, float* dev_buffer) {
 int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !out_host) return fail(h, NMPC_E_ARG, "null argument");
-    if (b < 0 || b >= h->dims.B_max || k < 0 || k >= h->dims.N || which < 0 || which >= nmpc::WS_TILES)
+    if (b < 0 || b >= h->dims.B_max || k < 0 || k >= h->dims.N || which < 0 || which > 3)
         return fail(h, NMPC_E_ARG, "index out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     const size_t N = h->dims.N;
-    const float* src = h->ws + ((size_t)b * nmpc::WS_TILES * N + (size_t)which * N + k) * nmpc::TILE;
+    const size_t off[4] = {0, N, 2 * N, 3 * N + 1};
+    const float* src = h->ws + ((size_t)b * nmpc::ws_tiles((int)N) + off[which] + k) * nmpc::TILE;
     HIP_TRY(h, hipMemcpy(out_host, src, nmpc::TILE * sizeof(float), hipMemcpyDeviceToHost));
     return NMPC_OK;
 }

@@ -54,7 +54,9 @@ struct DoubleIntegrator {
     __device__ static void gdot(const ModelParams&, const float (&v)[NU], float (&o)[NG]) {
         o[0] = v[0]; o[1] = -v[0]; o[2] = v[1]; o[3] = -v[1];
     }
-    // inputs that couple with others in Huu (all of them here)
+    // inputs that couple with others in Huu: all of them, always -> one static variant
+    static constexpr int N_STATIC_MASKS = 1;
+    __host__ __device__ static constexpr unsigned static_mask(int) { return 0x3u; }
     __device__ static unsigned input_mask(const ModelParams&, const float*) { return 0x3u; }
 };
 
@@ -273,6 +275,13 @@ struct Centroidal {
 #pragma unroll
         for (int f = 0; f < 4; ++f) m |= (p[f] > 0.5f) ? (0x7u << (3 * f)) : 0u;
         return m;
+    }
+    // coupling masks that get a fully static stage body: the two diagonal stance pairs of a trot
+    // (contact_planner.py:45-118, offsets [.5,0,0,.5]), four-foot stance and flight; any other
+    // contact pattern takes the run-time-mask fallback.
+    static constexpr int N_STATIC_MASKS = 4;
+    __host__ __device__ static constexpr unsigned static_mask(int i) {
+        return i == 0 ? 0xE07u : i == 1 ? 0x1F8u : i == 2 ? 0xFFFu : 0x000u;
     }
     __device__ static void gdot(const ModelParams& mp, const float (&v)[NU], float (&o)[NG]) {
 #pragma unroll

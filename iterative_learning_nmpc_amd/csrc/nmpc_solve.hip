@@ -41,7 +41,8 @@ struct SolveArgs {
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
-constexpr int WS_TILES = 4;        // workspace tiles per stage: A~, B~, K~', Acl~'
+// workspace tiles per problem: A~[N], B~[N], K~'[N+1], Acl~'[N+1]
+__host__ __device__ inline size_t ws_tiles(int N) { return 4 * (size_t)N + 2; }
 constexpr int N_LANE_STAGES = 2;   // lane = stage phases keep per-stage data in registers: N <= 128
 
 // Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
@@ -126,10 +127,10 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     const float* yr = a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY);
     const float* yre = a.yref_e + (size_t)b * NX;
     const float* x0 = a.x0 + (size_t)b * NX;
-    float* At = a.ws + (size_t)b * WS_TILES * N * TILE;
+    float* At = a.ws + (size_t)b * ws_tiles(N) * TILE;
     float* Bt = At + (size_t)N * TILE;
-    float* Kt = Bt + (size_t)N * TILE;   // transposed images of K~
-    float* Ct = Kt + (size_t)N * TILE;   // transposed images of Acl~ = A~ + B~K~
+    float* Kt = Bt + (size_t)N * TILE;         // transposed images of K~ (N + 1 scratch slot)
+    float* Ct = Kt + (size_t)(N + 1) * TILE;   // transposed images of Acl~ = A~ + B~K~ (N + 1)
 
     for (int i = lane; i < L.conv; i += 64) smem[i] = 0.0f;   // padding entries stay finite
     wave_sync();
@@ -289,60 +290,147 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                     P[r] = v;
                 }
             }
-            // Stage tiles are prefetched TWO stages ahead.  The wave is alone on its SIMD at
-            // B = 1024, so nothing else hides the L2 / Infinity-Cache latency; and because vmcnt
-            // retires in issue order, a distance of two keeps each stage's K~/Acl~ stores
-            // younger than the loads the next stage waits for (no stall on store completion).
+            // Software-pipelined backward sweep.  The wave is alone on its SIMD at B = 1024, so
+            // nothing else hides latency: stage tiles are prefetched one stage ahead, and the work
+            // that is off the critical path (K~/Acl~ of the previous stage + their stores, cost
+            // tiles of the next stage) is issued in the shadow of the elimination.
             auto sweep = [&](auto ipm_tag) {
                 constexpr bool IPM = decltype(ipm_tag)::value;
-                const int k1 = (N - 2 > 0) ? N - 2 : 0;
-                f32x4 A0 = load_tile(At + (size_t)(N - 1) * TILE, lane);
-                f32x4 B0 = load_tile(Bt + (size_t)(N - 1) * TILE, lane);
-                f32x4 T0 = load_tile_t(Bt + (size_t)(N - 1) * TILE, lane);
-                f32x4 A1 = load_tile(At + (size_t)k1 * TILE, lane);
-                f32x4 B1 = load_tile(Bt + (size_t)k1 * TILE, lane);
-                f32x4 T1 = load_tile_t(Bt + (size_t)k1 * TILE, lane);
-                for (int k = N - 1; k >= 0; --k) {
-#ifdef NMPC_STAMPS
-                    sst.t0 = __builtin_readcyclecounter();
-#endif
-                    const int kn = (k - 2 > 0) ? k - 2 : 0;
-                    const f32x4 A2 = load_tile(At + (size_t)kn * TILE, lane);
-                    const f32x4 B2 = load_tile(Bt + (size_t)kn * TILE, lane);
-                    const f32x4 T2 = load_tile_t(Bt + (size_t)kn * TILE, lane);
-                    f32x4 Qt, St, Rt = Rc;
+                // additive cost tiles of stage kk: Q~ = [Q q; q' 0], S~ = [0 r], R (+ barrier terms)
+                // operands of the additive cost tiles of stage kk: Q~ = [Q q; q' 0], S~ = [0 r], R, and
+                // for the barrier terms Gs = sqrt(D).G, Vt = (v/sqrt(D)) e_nx  (R += Gs'Gs, S~ += Gs'Vt)
+                auto cost_operands = [&](int kk, f32x4& Qt, f32x4& St, f32x4& Rt, f32x4& Gs, f32x4& Vt) {
+                    Rt = Rc;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float qe = AT(qv, k, qf[r]);
-                        const float re = AT(rv, k, rf[r]);
+                        const float qe = AT(qv, kk, qf[r]);
+                        const float re = AT(rv, kk, rf[r]);
                         Qt[r] = Qc[r] + (qm[r] ? qe : 0.0f);
                         St[r] = rm[r] ? re : 0.0f;
                     }
                     if constexpr (IPM) {
-                        f32x4 Gs, Vt;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float sq = AT(gsq, k, gf[r]);
-                            const float vt = AT(gvt, k, gf[r]);
+                            const float sq = AT(gsq, kk, gf[r]);
+                            const float vt = AT(gvt, kk, gf[r]);
                             Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
                             Vt[r] = (gm[r] && is_hx_col) ? vt : 0.0f;
                         }
-                        Rt = xty(Gs, Gs, Rt);
-                        St = xty(Gs, Vt, St);
                     }
-                    f32x4 Kk, Acl;
-                    SST_TILES(6);
-                    qp_ok = backward_stage<NU>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane, umask[k], Kk, Acl SST_PASS) && qp_ok;
-#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
-                    store_tile_t(Kt + (size_t)k * TILE, lane, Kk);
-                    store_tile_t(Ct + (size_t)k * TILE, lane, Acl);
-#else
-                    asm volatile("" ::"v"(Kk), "v"(Acl));
+                };
+                f32x4 A0 = load_tile(At + (size_t)(N - 1) * TILE, lane);
+                f32x4 B0 = load_tile(Bt + (size_t)(N - 1) * TILE, lane);
+                f32x4 T0 = load_tile_t(Bt + (size_t)(N - 1) * TILE, lane);
+                f32x4 Qt, St, Rt;
+                {
+                    f32x4 Gs, Vt;
+                    cost_operands(N - 1, Qt, St, Rt, Gs, Vt);
+                    if constexpr (IPM) {
+                        Rt = xty(Gs, Gs, Rt);     // G'DG : the Gauss-Newton contraction of the barrier
+                        St = xty(Gs, Vt, St);     // G'v
+                    }
+                }
+                // factors of the stage finished last (its K~, Acl~ are formed in the next stage's
+                // shadow); the first stage's shadow writes zeros to the scratch slot N
+                f32x4 Wp = zero4(), Yp = zero4(), Ap = zero4(), Tp = zero4();
+                for (int k = N - 1; k >= 0; --k) {
+#ifdef NMPC_STAMPS
+                    sst.t0 = __builtin_readcyclecounter();
 #endif
+                    // next stage's tiles: issued first, consumed by the register rotation at the end
+                    // of this stage -- by then only this stage's K~/Acl~ stores are younger (vmcnt
+                    // retires in order), so neither the loads nor the stores ever stall the sweep
+#ifdef NMPC_EXP_SAMETILE   // timing experiment: every stage re-reads one (cache-resident) tile
+                    const int kn = 0;
+#else
+                    const int kn = (k > 0) ? k - 1 : 0;
+#endif
+                    const f32x4 A1 = load_tile(At + (size_t)kn * TILE, lane);
+                    const f32x4 B1 = load_tile(Bt + (size_t)kn * TILE, lane);
+                    const f32x4 T1 = load_tile_t(Bt + (size_t)kn * TILE, lane);
+                    f32x4 Wk, Yk;
+                    // shadow work of this stage: gain tiles of stage k+1 (slot N is scratch for the
+                    // first stage) and cost tiles of stage k-1
+                    struct Shadow {
+                        GainShadow g;
+                        f32x4 Gs, Vt, Qn, Sn, Rn;
+                        float *kdst, *cdst;
+                        int lane;
+                        // operand fetch for the next stage's cost tiles: issued after this stage's
+                        // column loads, so its LDS latency hides behind the elimination
+                        const float *qrow, *rrow, *sqrow, *vtrow;   // LDS rows of stage k-1
+                        const int *qf, *rf, *gf;
+                        const bool *qm, *rm, *gm;
+                        f32x4 Qc, Rc, Gc;
+                        int NS;
+                        bool hx_col;
+                        __device__ __forceinline__ void begin() {
+                            Rn = Rc;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float qe = qrow[qf[r] * NS];
+                                const float re = rrow[rf[r] * NS];
+                                Qn[r] = Qc[r] + (qm[r] ? qe : 0.0f);
+                                Sn[r] = rm[r] ? re : 0.0f;
+                            }
+                            if constexpr (IPM) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float sq = sqrow[gf[r] * NS];
+                                    const float vt = vtrow[gf[r] * NS];
+                                    Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
+                                    Vt[r] = (gm[r] && hx_col) ? vt : 0.0f;
+                                }
+                            }
+                        }
+                        __device__ __forceinline__ void mfma_k(int i) { g.mfma_k(i); }
+                        __device__ __forceinline__ void mfma_a(int i) { g.mfma_a(i); }
+                        __device__ __forceinline__ void mfma_r(int i) {
+                            if constexpr (IPM) Rn = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Gs[i], Rn, 0, 0, 0);
+                        }
+                        __device__ __forceinline__ void mfma_s(int i) {
+                            if constexpr (IPM) Sn = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Sn, 0, 0, 0);
+                        }
+                        __device__ __forceinline__ void end() {
+#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
+                            store_tile_t(kdst, lane, g.K);
+                            store_tile_t(cdst, lane, g.Acl);
+#else
+                            asm volatile("" ::"v"(g.K), "v"(g.Acl));
+#endif
+                        }
+                    } sh;
+                    sh.g.init(Wp, Yp, Ap, Tp);
+                    sh.kdst = Kt + (size_t)(k + 1) * TILE;
+                    sh.cdst = Ct + (size_t)(k + 1) * TILE;
+                    sh.lane = lane;
+                    {
+                        const int kc = k > 0 ? k - 1 : 0;
+                        sh.qrow = qv + kc; sh.rrow = rv + kc; sh.sqrow = gsq + kc; sh.vtrow = gvt + kc;
+                        sh.qf = qf; sh.rf = rf; sh.gf = gf; sh.qm = qm; sh.rm = rm; sh.gm = gm;
+                        sh.Qc = Qc; sh.Rc = Rc; sh.Gc = Gc; sh.NS = NS; sh.hx_col = is_hx_col;
+                    }
+                    const unsigned cm = umask[k];
+                    auto run = [&](auto mask_tag) {
+                        return backward_stage<NU, decltype(mask_tag)::value>(P, A0, B0, Qt, St, Rt, conv, sl, lane,
+                                                                             cm, Wk, Yk, sh SST_PASS);
+                    };
+                    bool ok;
+                    if (cm == M::static_mask(0)) ok = run(std::integral_constant<unsigned, M::static_mask(0)>{});
+                    else if (M::N_STATIC_MASKS > 1 && cm == M::static_mask(1)) ok = run(std::integral_constant<unsigned, M::static_mask(1)>{});
+                    else if (M::N_STATIC_MASKS > 2 && cm == M::static_mask(2)) ok = run(std::integral_constant<unsigned, M::static_mask(2)>{});
+                    else if (M::N_STATIC_MASKS > 3 && cm == M::static_mask(3)) ok = run(std::integral_constant<unsigned, M::static_mask(3)>{});
+                    else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
+                    qp_ok = ok && qp_ok;
+                    Wp = Wk; Yp = Yk; Ap = A0; Tp = T0;
                     A0 = A1; B0 = B1; T0 = T1;
-                    A1 = A2; B1 = B2; T1 = T2;
+                    Qt = sh.Qn; St = sh.Sn; Rt = sh.Rn;
                     SST_TILES(5);
                 }
+                f32x4 Kk, Acl;
+                gain_tiles(Wp, Yp, Ap, Tp, Kk, Acl);
+                store_tile_t(Kt, lane, Kk);
+                store_tile_t(Ct, lane, Acl);
             };
             if (use_ipm) sweep(std::true_type{}); else sweep(std::false_type{});
             __threadfence_block();

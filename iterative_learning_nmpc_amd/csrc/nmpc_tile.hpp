@@ -105,24 +105,43 @@ __device__ __forceinline__ f32x4 lds_load_acc(const float* t, int lane) {
 // Returns false if a pivot is not positive (status "QP failure").
 // `coupled`: bit j set if input j may couple with other inputs.  A pivot whose column is exactly
 // diagonal (a masked-out input: zero column of B, no active constraint row) has all multipliers
-// equal to zero, so its update loop is skipped -- bit-identical result, wave-uniform branch.
-template <int NU>
-__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled = 0xFFFFFFFFu) {
+// equal to zero, so its update loop is skipped -- bit-identical result.
+//   MASK != DYNAMIC_MASK: the mask is a compile-time constant; inactive pivots AND inactive rows
+//   vanish from the unrolled code and the elimination is straight-line code.
+//   MASK == DYNAMIC_MASK: run-time mask, one wave-uniform branch per pivot.
+// after(j) is called behind pivot j between two scheduling fences: the caller issues there the
+// MFMAs that are independent of the elimination, so that the matrix pipe works in the shadow of
+// this VALU/readlane chain (an in-order wave overlaps the two only if they alternate in program
+// order; left alone, hipcc clusters the MFMAs in front of the chain).
+constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
+#ifndef NMPC_INTERLEAVE
+#define NMPC_INTERLEAVE 0   // 1: pin two shadow MFMAs behind every pivot; 0: leave placement to hipcc
+#endif
+
+template <int NU, unsigned MASK, class After>
+__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, After&& after) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const float d = bcast(col[j], j);
         ok = ok && (d > 0.0f);
-        if ((coupled >> j) & 1u) {
+        if ((MASK == DYNAMIC_MASK) ? ((coupled >> j) & 1u) : ((MASK >> j) & 1u)) {
             const float rinv = fast_rcp(d);
             const float w = col[j] * rinv;
-            float l[NU];
 #pragma unroll
-            for (int i = j + 1; i < NU; ++i) l[i] = bcast(col[i], j);
-#pragma unroll
-            for (int i = j + 1; i < NU; ++i) col[i] = fmaf(-l[i], w, col[i]);
+            for (int i = j + 1; i < NU; ++i) {
+                if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
+                    const float l = bcast(col[i], j);
+                    col[i] = fmaf(-l, w, col[i]);
+                }
+            }
         }
         col[j] = col[j] * __builtin_amdgcn_rsqf(d);
+#if NMPC_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+        after(j);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     return ok;
 }
