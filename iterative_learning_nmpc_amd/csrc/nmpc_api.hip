@@ -19,6 +19,7 @@ struct Handle {
     int nx = 0, nu = 0, np = 0, ng = 0;
     float* ws = nullptr;
     size_t ws_bytes = 0;
+    size_t ws_stride = 0;    // floats per problem
     float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
@@ -44,15 +45,26 @@ int fail(Handle* h, int code, const std::string& msg) {
     } while (0)
 
 template <class M>
-int launch_solve(Handle* h, const nmpc::SolveArgs& a, hipStream_t st) {
+size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
+
+// One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
+// finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
+template <class M>
+int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     const nmpc::Lds<M> L(a.N);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024 || a.N > 64 * nmpc::N_LANE_STAGES)
         return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
     if (bytes > 64 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_solve_kernel<M>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<M>, dim3(a.B), dim3(64), bytes, st, a);
+    const long long nthreads = (long long)a.B * (a.N + 1);
+    const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
+    for (int it = 0; it < a.max_sqp; ++it) {
+        a.it = it;
+        hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(nmpc::nmpc_qp_kernel<M>, dim3(a.B), dim3(64), bytes, st, a);
+    }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
 }
@@ -92,7 +104,10 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) {
-        h->ws_bytes = (size_t)dims->B_max * nmpc::ws_tiles(dims->N) * nmpc::TILE * sizeof(float);
+        h->ws_stride = (dims->model_id == NMPC_MODEL_DOUBLE_INTEGRATOR)
+                           ? ws_floats_per_problem<nmpc::DoubleIntegrator>(dims->N)
+                           : ws_floats_per_problem<nmpc::Centroidal>(dims->N);
+        h->ws_bytes = (size_t)dims->B_max * h->ws_stride * sizeof(float);
         e = hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes);
     }
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
@@ -274,8 +289,8 @@ int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     const size_t N = h->dims.N;
-    const size_t off[4] = {0, N, 2 * N, 3 * N + 1};
-    const float* src = h->ws + ((size_t)b * nmpc::ws_tiles((int)N) + off[which] + k) * nmpc::TILE;
+    const size_t off[4] = {0, N, 2 * N, 3 * N + 1};   // tile images lead every problem's workspace
+    const float* src = h->ws + (size_t)b * h->ws_stride + (off[which] + k) * nmpc::TILE;
     HIP_TRY(h, hipMemcpy(out_host, src, nmpc::TILE * sizeof(float), hipMemcpyDeviceToHost));
     return NMPC_OK;
 }

@@ -1,14 +1,20 @@
-// nmpc_solve.hip -- batched NMPC solve, one problem per wavefront (gfx950).
+// nmpc_solve.hip -- batched NMPC solve on gfx950: two kernels per SQP iteration.
 //
 // Replaces the reference's per-step solve (mpc_controller/utils/solver.py:396-403 ->
-// acados SQP / HPIPM) by one kernel launch per batch:
-//   phase L (lane = stage)  dynamics, analytic A,B, defects, gradients, constraint values
-//   phase R (serial stages)  Riccati backward on 16x16 tiles: MFMA products + readlane LDL'
-//   phase F (serial stages)  rollout of the affine feedback law (MFMA mat-vec)
-//   phase I (lane = stage)  interior-point step: slacks, multipliers, fraction to boundary
-//   phase S (lane = stage)  step (optionally l1-merit backtracking), write back
-// Stage matrices A~,B~,K~ live in an HBM/L2 workspace as 1 KiB column-major tile images;
-// trajectories, gradients and IPM state of the problem live in LDS (~32 KB at N=50).
+// acados SQP / HPIPM):
+//   nmpc_linearize_kernel  one thread per (problem, stage): dynamics, analytic A,B, defects,
+//                          gradients, constraint values -> workspace (fully parallel, any
+//                          register budget, no cross-lane traffic)
+//   nmpc_qp_kernel         one problem per wavefront: interior-point loop of Riccati sweeps
+//        phase R (serial stages)  backward sweep on 16x16 tiles: MFMA products + readlane LDL'
+//        phase F (serial stages)  rollout of the closed loop (MFMA mat-vec)
+//        phase I (lane = stage)   interior-point step: slacks, multipliers, fraction to boundary
+//        phase S (lane = stage)   step (optionally l1-merit backtracking), status, write back
+// Splitting the linearisation off keeps the sweep kernel's register allocation small (the
+// Jacobian code wants hundreds of VGPRs; fused, it forced the MFMA accumulators of the sweeps
+// through AGPR<->VGPR copies and pinned the kernel at one wave per SIMD).
+// Stage matrices A~,B~,K~',Acl~' live in an HBM/L2 workspace as 1 KiB tile images; trajectories,
+// gradients and IPM state of a problem live in LDS (~38 KB at N=50) inside nmpc_qp_kernel.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -26,6 +32,7 @@ struct SolveArgs {
     float reg, reg_e;
     int N, B;
     int max_sqp, n_ipm, line_search, yref_per_stage;
+    int it;               // SQP iteration this launch pair belongs to
     float nlp_tol, mu0, sigma, s_min, gamma, tau_min, rho;
     const float* x0;
     const float* yref;
@@ -35,15 +42,36 @@ struct SolveArgs {
     float* U;
     int* status;
     float* stats;
-    float* ws;            // workspace: per problem 3*N tiles (A~, B~, K~)
+    float* ws;            // workspace, WsLayout per problem
     float* dbg;           // diagnostic builds: [B][8] phase cycle counts, else unused
 };
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
-// workspace tiles per problem: A~[N], B~[N], K~'[N+1], Acl~'[N+1]
-__host__ __device__ inline size_t ws_tiles(int N) { return 4 * (size_t)N + 2; }
-constexpr int N_LANE_STAGES = 2;   // lane = stage phases keep per-stage data in registers: N <= 128
+// Workspace of one problem (float offsets): tile images A~[N], B~[N], K~'[N+1], Acl~'[N+1]
+// (the extra slot is scratch for the software pipeline), then what the linearisation hands to the
+// QP kernel: gradients q[N+1][nx], r[N][nu], constraint values c[N][ng], masks, stage costs, and
+// the problem's "finished" flag.
+template <class M>
+struct WsLayout {
+    size_t At, Bt, Kt, Ct, q, r, c, act, umk, cost, flag, stride;
+    __host__ __device__ explicit WsLayout(int N) {
+        size_t o = 0;
+        At = o; o += (size_t)N * TILE;
+        Bt = o; o += (size_t)N * TILE;
+        Kt = o; o += (size_t)(N + 1) * TILE;
+        Ct = o; o += (size_t)(N + 1) * TILE;
+        q = o; o += round4((N + 1) * M::NX);
+        r = o; o += round4(N * M::NU);
+        c = o; o += round4(N * M::NG);
+        act = o; o += round4(N);
+        umk = o; o += round4(N);
+        cost = o; o += round4(N + 1);
+        flag = o; o += 4;
+        stride = (o + 63) & ~(size_t)63;
+    }
+};
+constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N <= 256
 
 // Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
 // a buffer of their own; the production kernel contains no stamp.
@@ -98,16 +126,104 @@ __device__ __forceinline__ void store_col16(float* tile, int c, const float (&v)
         if (i < nquads) p[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
 }
 
+// ------------------------------------------------------------------------------------------------
+// Linearisation: thread t <-> (problem b, stage k), k = N is the terminal stage.
 template <class M>
-__global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     constexpr int NQ = (NX + 1 + 3) / 4;   // float4 per stored column (rows 0..NX)
+    const int N = a.N;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)a.B * (N + 1)) return;
+    const int b = (int)(t / (N + 1)), k = (int)(t - (long long)b * (N + 1));
+    const WsLayout<M> wl(N);
+    float* ws = a.ws + (size_t)b * wl.stride;
+    if (a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]) return;   // problem already finished
+    const float* Xg = a.X + (size_t)b * (N + 1) * NX;
+    const float* Ug = a.U + (size_t)b * N * NU;
+    float x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)k * NX + i];
+    if (k == N) {   // terminal gradient and cost
+        const float* yre = a.yref_e + (size_t)b * NX;
+        float cst = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const float e = x[i] - yre[i];
+            ws[wl.q + (size_t)N * NX + i] = a.We[i] * e;
+            cst += 0.5f * a.We[i] * e * e;
+        }
+        ws[wl.cost + N] = cst;
+        return;
+    }
+    float u[NU], xn[NX], p[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = Ug[(size_t)k * NU + i];
+    const float* pg = a.params + ((size_t)b * (N + 1) + k) * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = pg[i];
+    float* Atk = ws + wl.At + (size_t)k * TILE;
+    float* Btk = ws + wl.Bt + (size_t)k * TILE;
+    auto emitA = [&](int j, const float (&colv)[NX]) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
+        store_col16(Atk, j, v, NQ);
+    };
+    auto emitB = [&](int j, const float (&colv)[NX]) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
+        store_col16(Btk, j, v, NQ);
+    };
+    M::linearize(a.mp, x, u, p, xn, emitA, emitB);
+    {   // defect column  [d; 1]
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(k + 1) * NX + (i < NX ? i : 0)]
+                            : (i == NX ? 1.0f : 0.0f);
+        store_col16(Atk, NX, v, NQ);
+    }
+    const float* yk = a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) +
+                      (a.yref_per_stage ? (size_t)k * NY : 0);
+    float cst = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const float e = x[i] - yk[i];
+        ws[wl.q + (size_t)k * NX + i] = a.W[i] * e;
+        cst += 0.5f * a.W[i] * e * e;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const float e = u[i] - yk[NX + i];
+        ws[wl.r + (size_t)k * NU + i] = a.W[NX + i] * e;
+        cst += 0.5f * a.W[NX + i] * e * e;
+    }
+    ws[wl.cost + k] = cst;
+    reinterpret_cast<unsigned*>(ws + wl.umk)[k] = M::input_mask(a.mp, p);
+    reinterpret_cast<unsigned*>(ws + wl.act)[k] = (a.n_ipm > 0) ? M::active_mask(a.mp, p) : 0u;
+    float g[NG];
+    M::gdot(a.mp, u, g);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) ws[wl.c + (size_t)k * NG + j] = g[j] - M::h(a.mp, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// QP + step of one SQP iteration: one problem per wavefront.
+template <class M>
+__global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
     const int lane = lane_id();
     const int q4 = lane >> 4, c = lane & 15;
     const int N = a.N;
+    const WsLayout<M> wl(N);
+    float* ws = a.ws + (size_t)b * wl.stride;
+    int* flag = reinterpret_cast<int*>(ws + wl.flag);
+    if (a.it > 0 && flag[0]) return;             // finished in an earlier iteration
     const Lds<M> L(N);
     const int NS = L.NS;
     float* Xs = smem + L.Xs;   float* Us = smem + L.Us;
@@ -127,15 +243,43 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     const float* yr = a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY);
     const float* yre = a.yref_e + (size_t)b * NX;
     const float* x0 = a.x0 + (size_t)b * NX;
-    float* At = a.ws + (size_t)b * ws_tiles(N) * TILE;
-    float* Bt = At + (size_t)N * TILE;
-    float* Kt = Bt + (size_t)N * TILE;         // transposed images of K~ (N + 1 scratch slot)
-    float* Ct = Kt + (size_t)(N + 1) * TILE;   // transposed images of Acl~ = A~ + B~K~ (N + 1)
+    float* At = ws + wl.At;
+    float* Bt = ws + wl.Bt;
+    float* Kt = ws + wl.Kt;   // transposed images of K~ (N + 1 scratch slot)
+    float* Ct = ws + wl.Ct;   // transposed images of Acl~ = A~ + B~K~ (N + 1)
 
     for (int i = lane; i < L.conv; i += 64) smem[i] = 0.0f;   // padding entries stay finite
     wave_sync();
-    for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; AT(Xs, k, e - k * NX) = Xg[e]; }
-    for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; AT(Us, k, e - k * NU) = Ug[e]; }
+    for (int e = lane; e < (N + 1) * NX; e += 64) {
+        const int k = e / NX;
+        AT(Xs, k, e - k * NX) = Xg[e];
+        AT(qv, k, e - k * NX) = ws[wl.q + e];
+    }
+    for (int e = lane; e < N * NU; e += 64) {
+        const int k = e / NU;
+        AT(Us, k, e - k * NU) = Ug[e];
+        AT(rv, k, e - k * NU) = ws[wl.r + e];
+    }
+    float cost_l = 0.0f, mu_l = 0.0f;
+    int nact_l = 0;
+    for (int e = lane; e < N * NG; e += 64) {
+        const int k = e / NG, j = e - k * NG;
+        const float cj = ws[wl.c + e];
+        const float s = fmaxf(-cj, a.s_min);
+        AT(cv, k, j) = cj;
+        AT(sv, k, j) = s;
+        AT(lv, k, j) = a.mu0 / s;
+    }
+    for (int k = lane; k <= N; k += 64) {
+        cost_l += ws[wl.cost + k];
+        if (k < N) {
+            const unsigned am = reinterpret_cast<const unsigned*>(ws + wl.act)[k];
+            actm[k] = am;
+            umask[k] = reinterpret_cast<const unsigned*>(ws + wl.umk)[k];
+            nact_l += __popc(am);
+            mu_l += a.mu0 * (float)__popc(am);      // s * (mu0 / s) per active row
+        }
+    }
     // per-lane weights of "its" column
     const float wq_c = (c < NX) ? a.W[c] + a.reg : 0.0f;
     const float wr_c = (c < NU) ? a.W[NX + (c < NU ? c : 0)] + a.reg : 0.0f;
@@ -165,88 +309,12 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     wave_sync();
 
     int status = NMPC_STATUS_MAXITER;
+    bool finished = false;
     STAMP_DECL;
     float cost = 0.0f, stepn = 0.0f, alpha = 1.0f;
-    int it = 0;
-    for (it = 0; it < a.max_sqp; ++it) {
-        // ------------------------------------------------------------ phase L: linearise
-        float cost_l = 0.0f, mu_l = 0.0f;
-        int nact_l = 0;
-        for (int k = lane; k < N; k += 64) {
-            float x[NX], u[NU], xn[NX], p[NP > 0 ? NP : 1];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = AT(Xs, k, i);
-#pragma unroll
-            for (int i = 0; i < NU; ++i) u[i] = AT(Us, k, i);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) p[i] = pg[(size_t)k * NP + i];
-            float* Atk = At + (size_t)k * TILE;
-            float* Btk = Bt + (size_t)k * TILE;
-            auto emitA = [&](int j, const float (&colv)[NX]) {
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
-                store_col16(Atk, j, v, NQ);
-            };
-            auto emitB = [&](int j, const float (&colv)[NX]) {
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
-                store_col16(Btk, j, v, NQ);
-            };
-            M::linearize(a.mp, x, u, p, xn, emitA, emitB);
-            {   // defect column  [d; 1]
-                float v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    v[i] = (i < NX) ? xn[i < NX ? i : 0] - AT(Xs, k + 1, i < NX ? i : 0)
-                                    : (i == NX ? 1.0f : 0.0f);
-                store_col16(Atk, NX, v, NQ);
-            }
-            const float* yk = yr + (a.yref_per_stage ? (size_t)k * NY : 0);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const float e = x[i] - yk[i];
-                AT(qv, k, i) = a.W[i] * e;
-                cost_l += 0.5f * a.W[i] * e * e;
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const float e = u[i] - yk[NX + i];
-                AT(rv, k, i) = a.W[NX + i] * e;
-                cost_l += 0.5f * a.W[NX + i] * e * e;
-            }
-            umask[k] = M::input_mask(a.mp, p);
-            if (a.n_ipm > 0) {
-                const unsigned am = M::active_mask(a.mp, p);
-                actm[k] = am;
-                nact_l += __popc(am);
-                float g[NG];
-                M::gdot(a.mp, u, g);
-#pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    const float cj = g[j] - M::h(a.mp, j);
-                    const float s = fmaxf(-cj, a.s_min);
-                    AT(cv, k, j) = cj;
-                    AT(sv, k, j) = s;
-                    AT(lv, k, j) = a.mu0 / s;
-                    if ((am >> j) & 1u) mu_l += a.mu0;      // s * (mu0 / s)
-                }
-            }
-        }
-        if (lane < NX) {
-            const float e = AT(Xs, N, lane) - yre[lane];
-            AT(qv, N, lane) = a.We[lane] * e;
-            cost_l += 0.5f * a.We[lane] * e * e;
-        }
-        for (int i = lane; i < NX * NS; i += 64) dX[i] = 0.0f;
-        for (int i = lane; i < NU * NS; i += 64) dU[i] = 0.0f;
+    {
         cost = wave_sum(cost_l);
         const int n_act = (int)(wave_sum((float)nact_l) + 0.5f);
-        // make the tile stores of this wave visible to its own later loads
-        __threadfence_block();
-        wave_sync();
-
         STAMP(0);
         // ------------------------------------------------------------ QP: interior point loop
         const bool use_ipm = (a.n_ipm > 0) && (n_act > 0);
@@ -326,8 +394,15 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                     f32x4 Gs, Vt;
                     cost_operands(N - 1, Qt, St, Rt, Gs, Vt);
                     if constexpr (IPM) {
-                        Rt = xty(Gs, Gs, Rt);     // G'DG : the Gauss-Newton contraction of the barrier
-                        St = xty(Gs, Vt, St);     // G'v
+                        f32x4 GV;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) GV[r] = is_hx_col ? Vt[r] : Gs[r];
+                        const f32x4 T = xty(Gs, GV);   // [G'DG | G'v]: the Gauss-Newton contraction of the barrier
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            Rt[r] += is_hx_col ? 0.0f : T[r];
+                            St[r] += is_hx_col ? T[r] : 0.0f;
+                        }
                     }
                 }
                 // factors of the stage finished last (its K~, Acl~ are formed in the next stage's
@@ -379,19 +454,28 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                                     const float sq = sqrow[gf[r] * NS];
                                     const float vt = vtrow[gf[r] * NS];
                                     Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
-                                    Vt[r] = (gm[r] && hx_col) ? vt : 0.0f;
+                                    Vt[r] = gm[r] ? (hx_col ? vt : Gs[r]) : 0.0f;   // [Gs | vt]
                                 }
+                                Tb = zero4();
                             }
                         }
                         __device__ __forceinline__ void mfma_k(int i) { g.mfma_k(i); }
                         __device__ __forceinline__ void mfma_a(int i) { g.mfma_a(i); }
+                        // barrier terms in ONE product: T = Gs'[Gs | vt] holds G'DG in its columns < nu and
+                        // G'v in column nx; end() splits it onto R and S~ (the Gauss-Newton contraction)
+                        f32x4 Tb;
                         __device__ __forceinline__ void mfma_r(int i) {
-                            if constexpr (IPM) Rn = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Gs[i], Rn, 0, 0, 0);
+                            if constexpr (IPM) Tb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Tb, 0, 0, 0);
                         }
-                        __device__ __forceinline__ void mfma_s(int i) {
-                            if constexpr (IPM) Sn = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Sn, 0, 0, 0);
-                        }
+                        __device__ __forceinline__ void mfma_s(int) {}
                         __device__ __forceinline__ void end() {
+                            if constexpr (IPM) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    Rn[r] += hx_col ? 0.0f : Tb[r];     // columns >= nu of Tb are zero
+                                    Sn[r] += hx_col ? Tb[r] : 0.0f;
+                                }
+                            }
 #ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
                             store_tile_t(kdst, lane, g.K);
                             store_tile_t(cdst, lane, g.Acl);
@@ -437,51 +521,49 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             wave_sync();
             STAMP(2);
             // -------------------------------------------------------- phase F: forward sweep
-            // dx~+ = Acl~ dx~ ,  du = K~ dx~ : one dependent MFMA group per stage; the two tiles
-            // of a stage are prefetched FWD_PF stages ahead (a stage is shorter than an L2 miss).
+            // dx~+ = Acl~ dx~ , du = K~ dx~ as ONE row-per-lane mat-vec: lane L < 16 holds row L of
+            // Acl~ (the stored image is row-major), lane 16+j row j of K~; dx~ is wave-uniform (SGPRs,
+            // refreshed by v_readlane).  13 FMAs + 13 readlanes per stage -- fp32 MFMA shares the
+            // VALU's FMA pipes (no overlap for one wave), so the 16-column MFMA mat-vec cost 8x32 cycles.
+            // Rows are prefetched FWD_PF stages ahead (a stage is shorter than an L2 miss).
             float* oX = use_ipm ? dXp : dX;
             float* oU = use_ipm ? dUp : dU;
-            f32x4 v;
+            float vs[NX + 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * q4 + r;
-                float t = 0.0f;
-                if (c == 0 && row < NX) t = x0[row < NX ? row : 0] - AT(Xs, 0, row < NX ? row : 0);
-                if (c == 0 && row == NX) t = 1.0f;
-                v[r] = t;
-            }
-            if (c == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * q4 + r < NX) AT(oX, 0, 4 * q4 + r) = v[r];
-            }
-            constexpr int FWD_PF = 4;
-            f32x4 Kr[FWD_PF], Cr[FWD_PF];
+            for (int i = 0; i < NX; ++i) vs[i] = x0[i] - AT(Xs, 0, i);
+            vs[NX] = 1.0f;
+            if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
+            constexpr int FWD_PF = 4, RQ4 = (NX + 1 + 3) / 4;
+            const bool is_x = lane < NX, is_u = (lane >= 16 && lane < 16 + NU);
+            const float* rowbase = ((lane < 16) ? Ct : Kt) + ((lane < 32) ? (lane & 15) : 0) * TS;
+            float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
+            const int dstep = (is_x || is_u) ? 1 : 0;
+            f32x4 ring[FWD_PF][RQ4];
 #pragma unroll
             for (int j = 0; j < FWD_PF; ++j) {
                 const int kk = (j < N) ? j : N - 1;
-                Kr[j] = load_tile(Kt + (size_t)kk * TILE, lane);   // K~' of stage kk
-                Cr[j] = load_tile(Ct + (size_t)kk * TILE, lane);   // Acl~'
+#pragma unroll
+                for (int i4 = 0; i4 < RQ4; ++i4)
+                    ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kk * TILE + 4 * i4);
             }
             for (int k0 = 0; k0 < N; k0 += FWD_PF) {
 #pragma unroll
                 for (int j = 0; j < FWD_PF; ++j) {
                     const int k = k0 + j;
                     if (k >= N) break;
-                    const f32x4 Kc = Kr[j], Cc = Cr[j];
-                    const int kn = (k + FWD_PF < N) ? k + FWD_PF : N - 1;
-                    Kr[j] = load_tile(Kt + (size_t)kn * TILE, lane);
-                    Cr[j] = load_tile(Ct + (size_t)kn * TILE, lane);
-                    const f32x4 du = xty(Kc, v);
-                    v = xty(Cc, v);
-                    if (c == 0) {
+                    f32x4 row[RQ4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 4 * q4 + r;
-                            if (row < NU) AT(oU, k, row) = du[r];
-                            if (row < NX) AT(oX, k + 1, row) = v[r];
-                        }
-                    }
+                    for (int i4 = 0; i4 < RQ4; ++i4) row[i4] = ring[j][i4];
+                    const int kn = (k + FWD_PF < N) ? k + FWD_PF : N - 1;
+#pragma unroll
+                    for (int i4 = 0; i4 < RQ4; ++i4)
+                        ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kn * TILE + 4 * i4);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int i = 0; i <= NX; ++i) acc = fmaf(row[i >> 2][i & 3], vs[i], acc);
+                    dst[k * dstep] = acc;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) vs[i] = bcast(acc, i);
                 }
             }
             wave_sync();
@@ -489,11 +571,15 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
             // -------------------------------------------------------- phase I: IPM update
             if (use_ipm) {
                 float ap_l = 1.0f, ad_l = 1.0f;
-                float ds[(N_LANE_STAGES) * NG], dl[(N_LANE_STAGES) * NG];
-#pragma unroll
-                for (int ks = 0; ks < N_LANE_STAGES; ++ks) {
-                    const int k = lane + 64 * ks;
-                    if (k >= N) break;
+                // ds = -(G du+ + c) - s ;  dlam = tau/s - lam - (lam/s) ds   (recomputed in the
+                // second pass rather than kept in runtime-indexed arrays, which would go to scratch)
+                auto step_dir = [&](int k, int j, const float (&g)[NG], float& s, float& l, float& dsj, float& dlj) {
+                    s = AT(sv, k, j); l = AT(lv, k, j);
+                    const float is = fast_rcp(s);
+                    dsj = -(g[j] + AT(cv, k, j)) - s;
+                    dlj = tau * is - l - l * is * dsj;
+                };
+                for (int k = lane; k < N; k += 64) {
                     float du[NU], g[NG];
 #pragma unroll
                     for (int i = 0; i < NU; ++i) du[i] = AT(dUp, k, i);
@@ -501,31 +587,31 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
+                        float s, l, dsj, dlj;
+                        step_dir(k, j, g, s, l, dsj, dlj);
                         const bool on = (am >> j) & 1u;
-                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = AT(cv, k, j);
-                        const float is = fast_rcp(s);
-                        const float dsj = -(g[j] + cj) - s;
-                        const float dlj = tau * is - l - l * is * dsj;
-                        ds[ks * NG + j] = on ? dsj : 0.0f;
-                        dl[ks * NG + j] = on ? dlj : 0.0f;
                         if (on && dsj < 0.0f) ap_l = fminf(ap_l, -a.gamma * s / dsj);
                         if (on && dlj < 0.0f) ad_l = fminf(ad_l, -a.gamma * l / dlj);
                     }
                 }
                 const float ap = wave_min(ap_l), ad = wave_min(ad_l);
                 float m_l = 0.0f;
+                for (int k = lane; k < N; k += 64) {
+                    float du[NU], g[NG];
 #pragma unroll
-                for (int ks = 0; ks < N_LANE_STAGES; ++ks) {
-                    const int k = lane + 64 * ks;
-                    if (k >= N) break;
+                    for (int i = 0; i < NU; ++i) du[i] = AT(dUp, k, i);
+                    M::gdot(a.mp, du, g);
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
-                        const float s = AT(sv, k, j) + ap * ds[ks * NG + j];
-                        const float l = AT(lv, k, j) + ad * dl[ks * NG + j];
+                        float s, l, dsj, dlj;
+                        step_dir(k, j, g, s, l, dsj, dlj);
+                        const bool on = (am >> j) & 1u;
+                        s += on ? ap * dsj : 0.0f;
+                        l += on ? ad * dlj : 0.0f;
                         AT(sv, k, j) = s;
                         AT(lv, k, j) = l;
-                        if ((am >> j) & 1u) m_l += s * l;
+                        if (on) m_l += s * l;
                     }
                 }
                 mu_sum = wave_sum(m_l);
@@ -550,9 +636,9 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
         }
         stepn = wave_max(sn_l);
         const bool bad = __any(bad_l);
-        if (bad) { status = NMPC_STATUS_NAN; ++it; break; }
+        if (bad) { status = NMPC_STATUS_NAN; finished = true; }
         alpha = 1.0f;
-        if (a.line_search) {
+        if (a.line_search && !bad) {
             // l1 merit: cost + rho * (|x0 - X0| + sum |defects| + sum max(0, G u - h))
             auto merit = [&](float al) -> float {
                 float m_l = 0.0f;
@@ -603,14 +689,18 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
                 alpha *= 0.5f;
             }
         }
-        for (int i = lane; i < NX * NS; i += 64) Xs[i] += alpha * dX[i];
-        for (int i = lane; i < NU * NS; i += 64) Us[i] += alpha * dU[i];
-        wave_sync();
-        if (!qp_ok) { status = NMPC_STATUS_QP; ++it; break; }
-        if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; ++it; break; }
+        if (!bad) {
+            for (int i = lane; i < NX * NS; i += 64) Xs[i] += alpha * dX[i];
+            for (int i = lane; i < NU * NS; i += 64) Us[i] += alpha * dU[i];
+            wave_sync();
+            if (!qp_ok) { status = NMPC_STATUS_QP; finished = true; }
+            else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }
+        }
     }
-    for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; Xg[e] = AT(Xs, k, e - k * NX); }
-    for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; Ug[e] = AT(Us, k, e - k * NU); }
+    if (status != NMPC_STATUS_NAN) {   // a NaN step leaves the iterate of the previous iteration
+        for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; Xg[e] = AT(Xs, k, e - k * NX); }
+        for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; Ug[e] = AT(Us, k, e - k * NU); }
+    }
     STAMP(5);
 #ifdef NMPC_STAMPS
     if (lane == 0 && a.dbg) {
@@ -619,12 +709,13 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const SolveArgs a) {
     }
 #endif
     if (lane == 0) {
+        flag[0] = finished ? 1 : 0;
         if (a.status) a.status[b] = status;
         if (a.stats) {
             a.stats[4 * b + 0] = cost;
             a.stats[4 * b + 1] = stepn;
             a.stats[4 * b + 2] = alpha;
-            a.stats[4 * b + 3] = (float)it;
+            a.stats[4 * b + 3] = (float)(a.it + 1);
         }
     }
 #undef AT
