@@ -128,23 +128,35 @@ __device__ __forceinline__ void store_col16(float* tile, int c, const float (&v)
 
 // ------------------------------------------------------------------------------------------------
 // Linearisation: thread t <-> (problem b, stage k), k = N is the terminal stage.
+// A thread owns a whole 1 KiB tile, so storing it directly would make every wave store touch 64
+// different tiles with 16 B each.  Columns therefore go through a 4 KiB LDS stage: the block
+// re-distributes one column of 64 stages so that four lanes write the 64 contiguous bytes of a
+// stage's column (16 tiles x 64 B per store instruction instead of 64 x 16 B).
 template <class M>
 __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     constexpr int NQ = (NX + 1 + 3) / 4;   // float4 per stored column (rows 0..NX)
+    __shared__ __attribute__((aligned(16))) float stage_col[64 * 16];
+    __shared__ float* tile_of[2][64];       // A~ / B~ tile of each thread's stage (nullptr: none)
     const int N = a.N;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)a.B * (N + 1)) return;
-    const int b = (int)(t / (N + 1)), k = (int)(t - (long long)b * (N + 1));
+    const int tid = threadIdx.x;
+    const long long t = (long long)blockIdx.x * blockDim.x + tid;
+    const bool in_range = t < (long long)a.B * (N + 1);
+    const int b = in_range ? (int)(t / (N + 1)) : 0;
+    const int k = in_range ? (int)(t - (long long)b * (N + 1)) : N;
     const WsLayout<M> wl(N);
     float* ws = a.ws + (size_t)b * wl.stride;
-    if (a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]) return;   // problem already finished
+    const bool live = in_range && !(a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]);
+    const bool stage = live && k < N;       // this thread linearises a shooting interval
+    const int ks = stage ? k : 0;
     const float* Xg = a.X + (size_t)b * (N + 1) * NX;
     const float* Ug = a.U + (size_t)b * N * NU;
+    tile_of[0][tid] = stage ? ws + wl.At + (size_t)k * TILE : nullptr;
+    tile_of[1][tid] = stage ? ws + wl.Bt + (size_t)k * TILE : nullptr;
     float x[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)k * NX + i];
-    if (k == N) {   // terminal gradient and cost
+    for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)(live ? k : 0) * NX + i];
+    if (live && k == N) {   // terminal gradient and cost
         const float* yre = a.yref_e + (size_t)b * NX;
         float cst = 0.0f;
 #pragma unroll
@@ -154,37 +166,53 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
             cst += 0.5f * a.We[i] * e * e;
         }
         ws[wl.cost + N] = cst;
-        return;
     }
     float u[NU], xn[NX], p[NP > 0 ? NP : 1];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) u[i] = Ug[(size_t)k * NU + i];
-    const float* pg = a.params + ((size_t)b * (N + 1) + k) * NP;
+    for (int i = 0; i < NU; ++i) u[i] = Ug[(size_t)ks * NU + i];
+    const float* pg = a.params + ((size_t)b * (N + 1) + ks) * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) p[i] = pg[i];
-    float* Atk = ws + wl.At + (size_t)k * TILE;
-    float* Btk = ws + wl.Bt + (size_t)k * TILE;
+    __syncthreads();
+    // every thread of the block takes part in every column flush (idle threads carry a null tile)
+    auto flush = [&](int which, int j, const float (&v)[16]) {
+        f32x4* mine = reinterpret_cast<f32x4*>(stage_col + tid * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        __syncthreads();
+        const int quad = tid & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = (tid >> 2) + 16 * i;
+            float* tile = tile_of[which][s];
+            if (tile != nullptr && quad < NQ)
+                *reinterpret_cast<f32x4*>(tile + j * TS + 4 * quad) =
+                    *reinterpret_cast<const f32x4*>(stage_col + s * 16 + 4 * quad);
+        }
+        __syncthreads();
+    };
     auto emitA = [&](int j, const float (&colv)[NX]) {
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
-        store_col16(Atk, j, v, NQ);
+        flush(0, j, v);
     };
     auto emitB = [&](int j, const float (&colv)[NX]) {
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = (i < NX) ? colv[i < NX ? i : 0] : 0.0f;
-        store_col16(Btk, j, v, NQ);
+        flush(1, j, v);
     };
     M::linearize(a.mp, x, u, p, xn, emitA, emitB);
     {   // defect column  [d; 1]
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(k + 1) * NX + (i < NX ? i : 0)]
+            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(ks + 1) * NX + (i < NX ? i : 0)]
                             : (i == NX ? 1.0f : 0.0f);
-        store_col16(Atk, NX, v, NQ);
+        flush(0, NX, v);
     }
+    if (!stage) return;
     const float* yk = a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) +
                       (a.yref_per_stage ? (size_t)k * NY : 0);
     float cst = 0.0f;

@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
-kname = sys.argv[3] if len(sys.argv) > 3 else "nmpc_solve_kernel"
+kname = sys.argv[3] if len(sys.argv) > 3 else "nmpc_qp_kernel"
 out = [f"# rocprofv3 summary: {os.path.basename(src)}", ""]
 for f in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
     out += ["## kernel-trace --stats (all kernels, top 6)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
