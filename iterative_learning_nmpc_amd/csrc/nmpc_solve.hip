@@ -88,13 +88,13 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 #define SST_TILES(i)
 #endif
 
-// LDS layout of one problem.  Every per-stage array is FEATURE-major, [feature][stage] with an odd
-// stage stride NS: the lane = stage phases touch consecutive banks, and the stage sweeps (lanes
-// differ in the feature) stay conflict-free because NS is odd.
+// LDS layout of one problem.  Arrays of the lane = stage phases (trajectories, steps, slacks,
+// multipliers) are FEATURE-major, [feature][stage] with an odd stage stride NS, so consecutive lanes
+// touch consecutive banks.
 template <class M>
 struct Lds {
     int NS;   // stage stride (odd, >= N+1)
-    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, cv, gsq, gvt, act, umk, conv, total;   // float offsets
+    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, gsq, gvt, act, umk, conv, total;   // float offsets
     __host__ __device__ explicit Lds(int N) {
         NS = (N + 1) | 1;
         int o = 0;
@@ -104,13 +104,14 @@ struct Lds {
         dU = o;  o += round4(M::NU * NS);
         dXp = o; o += round4(M::NX * NS);
         dUp = o; o += round4(M::NU * NS);
-        qv = o;  o += round4(M::NX * NS);
-        rv = o;  o += round4(M::NU * NS);
+        // sweep operands are STAGE-major, 16 floats per stage: the four tile registers of a lane
+        // are one 16 B read (only the stage sweeps touch them after they are written)
+        qv = o;  o += (N + 1) * TS;
+        rv = o;  o += N * TS;
+        gsq = o; o += N * TS;
+        gvt = o; o += N * TS;
         sv = o;  o += round4(M::NG * NS);
         lv = o;  o += round4(M::NG * NS);
-        cv = o;  o += round4(M::NG * NS);
-        gsq = o; o += round4(M::NG * NS);
-        gvt = o; o += round4(M::NG * NS);
         act = o; o += round4(NS);
         umk = o; o += round4(NS);
         conv = o; o += 3 * CTILE;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     float* dX = smem + L.dX;   float* dU = smem + L.dU;
     float* dXp = smem + L.dXp; float* dUp = smem + L.dUp;
     float* qv = smem + L.qv;   float* rv = smem + L.rv;
-    float* sv = smem + L.sv;   float* lv = smem + L.lv;   float* cv = smem + L.cv;
+    float* sv = smem + L.sv;   float* lv = smem + L.lv;
     float* gsq = smem + L.gsq; float* gvt = smem + L.gvt;
     unsigned* actm = reinterpret_cast<unsigned*>(smem + L.act);
     unsigned* umask = reinterpret_cast<unsigned*>(smem + L.umk);
@@ -281,20 +282,19 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     for (int e = lane; e < (N + 1) * NX; e += 64) {
         const int k = e / NX;
         AT(Xs, k, e - k * NX) = Xg[e];
-        AT(qv, k, e - k * NX) = ws[wl.q + e];
+        qv[k * TS + (e - k * NX)] = ws[wl.q + e];
     }
     for (int e = lane; e < N * NU; e += 64) {
         const int k = e / NU;
         AT(Us, k, e - k * NU) = Ug[e];
-        AT(rv, k, e - k * NU) = ws[wl.r + e];
+        rv[k * TS + (e - k * NU)] = ws[wl.r + e];
     }
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
     for (int e = lane; e < N * NG; e += 64) {
         const int k = e / NG, j = e - k * NG;
-        const float cj = ws[wl.c + e];
+        const float cj = ws[wl.c + e];           // c = G u - h at the linearisation point
         const float s = fmaxf(-cj, a.s_min);
-        AT(cv, k, j) = cj;
         AT(sv, k, j) = s;
         AT(lv, k, j) = a.mu0 / s;
     }
@@ -318,20 +318,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     SweepLane sl;
     sl.init(conv, lane, NX);
     f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
-    int qf[4], rf[4], gf[4];     // feature indices
-    bool qm[4], rm[4], gm[4];    // masks
+    bool qm[4], rm[4];           // masks: the register takes an element of q / r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * q4 + r;
         Qc[r] = (row == c && row < NX) ? wq_c : 0.0f;
         Rc[r] = (row == c && row < NU) ? wr_c : 0.0f;
         qm[r] = (c == NX && row < NX) || (row == NX && c < NX);
-        qf[r] = (c == NX) ? (row < NX ? row : 0) : (c < NX ? c : 0);
         rm[r] = (c == NX && row < NU);
-        rf[r] = (row < NU) ? row : 0;
-        gm[r] = row < NG;
-        gf[r] = (row < NG) ? row : 0;
-        Gc[r] = (row < NG && c < NU) ? M::G(a.mp, gf[r], c) : 0.0f;
+        Gc[r] = (row < NG && c < NU) ? M::G(a.mp, row < NG ? row : 0, c) : 0.0f;
     }
     const bool is_hx_col = (c == NX);
     wave_sync();
@@ -358,15 +353,19 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 tau = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
                 for (int k = lane; k < N; k += 64) {
                     const unsigned am = actm[k];
+                    float uk[NU], gk[NG];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) uk[i] = AT(Us, k, i);
+                    M::gdot(a.mp, uk, gk);
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
                         const bool on = (am >> j) & 1u;
-                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = AT(cv, k, j);
+                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = gk[j] - M::h(a.mp, j);
                         const float is = fast_rcp(s);
                         const float D = l * is;
                         const float rs = __builtin_amdgcn_rsqf(D);
-                        AT(gsq, k, j) = on ? D * rs : 0.0f;
-                        AT(gvt, k, j) = on ? (tau * is + l + D * cj) * rs : 0.0f;
+                        gsq[k * TS + j] = on ? D * rs : 0.0f;
+                        gvt[k * TS + j] = on ? (tau * is + l + D * cj) * rs : 0.0f;
                     }
                 }
                 wave_sync();
@@ -375,13 +374,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             // -------------------------------------------------------- phase R: backward sweep
             f32x4 P;
             {   // terminal: P~ = [diag(We)+reg_e, q_N; q_N', 0]
-                const float qc = (c < NX) ? AT(qv, N, c < NX ? c : 0) : 0.0f;
+                const float qc = (c < NX) ? qv[N * TS + (c < NX ? c : 0)] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * q4 + r;
                     float v = 0.0f;
                     if (row == c && row < NX) v = we_c;
-                    if (c == NX && row < NX) v = AT(qv, N, row < NX ? row : 0);
+                    if (c == NX && row < NX) v = qv[N * TS + (row < NX ? row : 0)];
                     if (row == NX && c < NX) v = qc;
                     P[r] = v;
                 }
@@ -397,20 +396,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 // for the barrier terms Gs = sqrt(D).G, Vt = (v/sqrt(D)) e_nx  (R += Gs'Gs, S~ += Gs'Vt)
                 auto cost_operands = [&](int kk, f32x4& Qt, f32x4& St, f32x4& Rt, f32x4& Gs, f32x4& Vt) {
                     Rt = Rc;
+                    const f32x4 q4v = *reinterpret_cast<const f32x4*>(qv + kk * TS + 4 * q4);   // q[4q..4q+3]
+                    const f32x4 r4v = *reinterpret_cast<const f32x4*>(rv + kk * TS + 4 * q4);
+                    const float qcv = qv[kk * TS + (c < NX ? c : 0)];                          // q[c]
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float qe = AT(qv, kk, qf[r]);
-                        const float re = AT(rv, kk, rf[r]);
-                        Qt[r] = Qc[r] + (qm[r] ? qe : 0.0f);
-                        St[r] = rm[r] ? re : 0.0f;
+                        Qt[r] = Qc[r] + (qm[r] ? (is_hx_col ? q4v[r] : qcv) : 0.0f);
+                        St[r] = rm[r] ? r4v[r] : 0.0f;
                     }
                     if constexpr (IPM) {
+                        const f32x4 sq4 = *reinterpret_cast<const f32x4*>(gsq + kk * TS + 4 * q4);
+                        const f32x4 vt4 = *reinterpret_cast<const f32x4*>(gvt + kk * TS + 4 * q4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float sq = AT(gsq, kk, gf[r]);
-                            const float vt = AT(gvt, kk, gf[r]);
-                            Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
-                            Vt[r] = (gm[r] && is_hx_col) ? vt : 0.0f;
+                            Gs[r] = Gc[r] * sq4[r];                 // rows >= ng: Gc = 0
+                            Vt[r] = is_hx_col ? vt4[r] : 0.0f;
                         }
                     }
                 };
@@ -461,28 +461,28 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                         int lane;
                         // operand fetch for the next stage's cost tiles: issued after this stage's
                         // column loads, so its LDS latency hides behind the elimination
-                        const float *qrow, *rrow, *sqrow, *vtrow;   // LDS rows of stage k-1
-                        const int *qf, *rf, *gf;
-                        const bool *qm, *rm, *gm;
+                        const float *qrow, *rrow, *sqrow, *vtrow;   // stage k-1: 16 B of this lane's row quad
+                        const float* qcol;                          // stage k-1: q[c]
+                        const bool *qm, *rm;
                         f32x4 Qc, Rc, Gc;
-                        int NS;
                         bool hx_col;
                         __device__ __forceinline__ void begin() {
                             Rn = Rc;
+                            const f32x4 q4v = *reinterpret_cast<const f32x4*>(qrow);
+                            const f32x4 r4v = *reinterpret_cast<const f32x4*>(rrow);
+                            const float qcv = *qcol;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float qe = qrow[qf[r] * NS];
-                                const float re = rrow[rf[r] * NS];
-                                Qn[r] = Qc[r] + (qm[r] ? qe : 0.0f);
-                                Sn[r] = rm[r] ? re : 0.0f;
+                                Qn[r] = Qc[r] + (qm[r] ? (hx_col ? q4v[r] : qcv) : 0.0f);
+                                Sn[r] = rm[r] ? r4v[r] : 0.0f;
                             }
                             if constexpr (IPM) {
+                                const f32x4 sq4 = *reinterpret_cast<const f32x4*>(sqrow);
+                                const f32x4 vt4 = *reinterpret_cast<const f32x4*>(vtrow);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const float sq = sqrow[gf[r] * NS];
-                                    const float vt = vtrow[gf[r] * NS];
-                                    Gs[r] = gm[r] ? Gc[r] * sq : 0.0f;
-                                    Vt[r] = gm[r] ? (hx_col ? vt : Gs[r]) : 0.0f;   // [Gs | vt]
+                                    Gs[r] = Gc[r] * sq4[r];                  // rows >= ng: Gc = 0
+                                    Vt[r] = hx_col ? vt4[r] : Gs[r];         // [Gs | vt]
                                 }
                                 Tb = zero4();
                             }
@@ -518,9 +518,11 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     sh.lane = lane;
                     {
                         const int kc = k > 0 ? k - 1 : 0;
-                        sh.qrow = qv + kc; sh.rrow = rv + kc; sh.sqrow = gsq + kc; sh.vtrow = gvt + kc;
-                        sh.qf = qf; sh.rf = rf; sh.gf = gf; sh.qm = qm; sh.rm = rm; sh.gm = gm;
-                        sh.Qc = Qc; sh.Rc = Rc; sh.Gc = Gc; sh.NS = NS; sh.hx_col = is_hx_col;
+                        sh.qrow = qv + kc * TS + 4 * q4; sh.rrow = rv + kc * TS + 4 * q4;
+                        sh.sqrow = gsq + kc * TS + 4 * q4; sh.vtrow = gvt + kc * TS + 4 * q4;
+                        sh.qcol = qv + kc * TS + (c < NX ? c : 0);
+                        sh.qm = qm; sh.rm = rm;
+                        sh.Qc = Qc; sh.Rc = Rc; sh.Gc = Gc; sh.hx_col = is_hx_col;
                     }
                     const unsigned cm = umask[k];
                     auto run = [&](auto mask_tag) {
@@ -601,22 +603,25 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 float ap_l = 1.0f, ad_l = 1.0f;
                 // ds = -(G du+ + c) - s ;  dlam = tau/s - lam - (lam/s) ds   (recomputed in the
                 // second pass rather than kept in runtime-indexed arrays, which would go to scratch)
-                auto step_dir = [&](int k, int j, const float (&g)[NG], float& s, float& l, float& dsj, float& dlj) {
+                auto step_dir = [&](int k, int j, const float (&g)[NG], const float (&cc)[NG], float& s, float& l, float& dsj, float& dlj) {
                     s = AT(sv, k, j); l = AT(lv, k, j);
                     const float is = fast_rcp(s);
-                    dsj = -(g[j] + AT(cv, k, j)) - s;
+                    dsj = -(g[j] + cc[j]) - s;
                     dlj = tau * is - l - l * is * dsj;
                 };
                 for (int k = lane; k < N; k += 64) {
-                    float du[NU], g[NG];
+                    float du[NU], g[NG], uk[NU], cc[NG];
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) du[i] = AT(dUp, k, i);
+                    for (int i = 0; i < NU; ++i) { du[i] = AT(dUp, k, i); uk[i] = AT(Us, k, i); }
                     M::gdot(a.mp, du, g);
+                    M::gdot(a.mp, uk, cc);          // c = G u - h, recomputed (kept out of LDS)
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) cc[j] -= M::h(a.mp, j);
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
                         float s, l, dsj, dlj;
-                        step_dir(k, j, g, s, l, dsj, dlj);
+                        step_dir(k, j, g, cc, s, l, dsj, dlj);
                         const bool on = (am >> j) & 1u;
                         if (on && dsj < 0.0f) ap_l = fminf(ap_l, -a.gamma * s / dsj);
                         if (on && dlj < 0.0f) ad_l = fminf(ad_l, -a.gamma * l / dlj);
@@ -625,15 +630,18 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 const float ap = wave_min(ap_l), ad = wave_min(ad_l);
                 float m_l = 0.0f;
                 for (int k = lane; k < N; k += 64) {
-                    float du[NU], g[NG];
+                    float du[NU], g[NG], uk[NU], cc[NG];
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) du[i] = AT(dUp, k, i);
+                    for (int i = 0; i < NU; ++i) { du[i] = AT(dUp, k, i); uk[i] = AT(Us, k, i); }
                     M::gdot(a.mp, du, g);
+                    M::gdot(a.mp, uk, cc);          // c = G u - h, recomputed (kept out of LDS)
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) cc[j] -= M::h(a.mp, j);
                     const unsigned am = actm[k];
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
                         float s, l, dsj, dlj;
-                        step_dir(k, j, g, s, l, dsj, dlj);
+                        step_dir(k, j, g, cc, s, l, dsj, dlj);
                         const bool on = (am >> j) & 1u;
                         s += on ? ap * dsj : 0.0f;
                         l += on ? ad * dlj : 0.0f;
