@@ -317,6 +317,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     // cost tiles of a stage are built with unconditional loads and selects (no branches)
     SweepLane sl;
     sl.init(conv, lane, NX);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sl.rs_free[j] = (j < NU) ? __builtin_amdgcn_rsqf(a.W[NX + (j < NU ? j : 0)] + a.reg) : 1.0f;
     f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
     bool qm[4], rm[4];           // masks: the register takes an element of q / r
 #pragma unroll

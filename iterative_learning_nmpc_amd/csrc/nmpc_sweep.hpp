@@ -40,6 +40,7 @@ struct SweepLane {
     bool from_lds;    // group < 2: column comes from the conversion tiles
     int ident_row;    // group 2: row of the 1 in the identity right-hand side, else -1
     bool corner[4];   // true at the (hx,hx) corner of a tile
+    float rs_free[16]; // 1/sqrt(R_jj + reg): scale of an uncoupled input's row (wave-uniform)
     __device__ __forceinline__ void init(float* conv, int lane, int hx) {
         const int t = lane >> 4, c = lane & 15;
         float* T0 = conv;
@@ -115,7 +116,10 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     for (int t = 0; t < MFMA_SLOTS; ++t) slot(t);
 #endif
 #ifndef NMPC_EXP_NOELIM
-    ok = ldl_eliminate<NU, MASK>(col, coupled, [&](int j) {
+    float rsf[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) rsf[j] = sl.rs_free[j];
+    ok = ldl_eliminate<NU, MASK>(col, coupled, rsf, [&](int j) {
 #pragma unroll
         for (int t = 0; t < PER; ++t) slot(j * PER + t);
     });
@@ -139,7 +143,7 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     const f32x4 W = mask_rows(lds_load_acc(conv, lane), lane, NU);
     wave_sync();
     SST(3);
-    f32x4 Pn = xty(-Y, Y, Hxx);
+    f32x4 Pn = xty2(-Y, Y, Hxx);
     // the constant term of the cost-to-go (corner hx,hx) feeds nothing: keep it at zero
 #pragma unroll
     for (int r = 0; r < 4; ++r) Pn[r] = sl.corner[r] ? 0.0f : Pn[r];

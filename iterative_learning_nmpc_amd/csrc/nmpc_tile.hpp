@@ -36,6 +36,18 @@ __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y, f32x4 C) {
 }
 __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y) { return xty(X, Y, zero4()); }
 
+// Same product with the K steps split over two accumulators: half the dependent-MFMA depth (a
+// dependent fp32 MFMA costs 44 cycles against 32 issue) for a product that stands alone on the
+// critical path.  X'X-type products stay bitwise symmetric (each half is).
+__device__ __forceinline__ f32x4 xty2(f32x4 X, f32x4 Y, f32x4 C) {
+    f32x4 D = zero4();
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], C, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], D, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[2], Y[2], C, 0, 0, 0);
+    D = __builtin_amdgcn_mfma_f32_16x16x4f32(X[3], Y[3], D, 0, 0, 0);
+    return C + D;
+}
+
 // wave-uniform value of lane `src` (src must be a compile-time constant after unrolling)
 __device__ __forceinline__ float bcast(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -118,25 +130,33 @@ constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
 #define NMPC_INTERLEAVE 0   // 1: pin two shadow MFMAs behind every pivot; 0: leave placement to hipcc
 #endif
 
+// rs_free[j] = 1/sqrt(pivot) of input j when it is uncoupled: its pivot is then the constant
+// R_jj + reg (nothing of B'PB or of the barrier reaches it), so a static mask needs neither the
+// broadcast nor the v_rsq for it.
 template <int NU, unsigned MASK, class After>
-__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, After&& after) {
+__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, const float (&rs_free)[NU],
+                                              After&& after) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
-        const float d = bcast(col[j], j);
-        ok = ok && (d > 0.0f);
-        if ((MASK == DYNAMIC_MASK) ? ((coupled >> j) & 1u) : ((MASK >> j) & 1u)) {
-            const float rinv = fast_rcp(d);
-            const float w = col[j] * rinv;
+        if (MASK != DYNAMIC_MASK && !((MASK >> j) & 1u)) {
+            col[j] = col[j] * rs_free[j];
+        } else {
+            const float d = bcast(col[j], j);
+            ok = ok && (d > 0.0f);
+            if (MASK != DYNAMIC_MASK || ((coupled >> j) & 1u)) {
+                const float rinv = fast_rcp(d);
+                const float w = col[j] * rinv;
 #pragma unroll
-            for (int i = j + 1; i < NU; ++i) {
-                if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
-                    const float l = bcast(col[i], j);
-                    col[i] = fmaf(-l, w, col[i]);
+                for (int i = j + 1; i < NU; ++i) {
+                    if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
+                        const float l = bcast(col[i], j);
+                        col[i] = fmaf(-l, w, col[i]);
+                    }
                 }
             }
+            col[j] = col[j] * __builtin_amdgcn_rsqf(d);
         }
-        col[j] = col[j] * __builtin_amdgcn_rsqf(d);
 #if NMPC_INTERLEAVE
         __builtin_amdgcn_sched_barrier(0);
         after(j);
