@@ -126,9 +126,8 @@ int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, cons
                         float *err, float *weight, float threshold, float ood_weight, void *stream);
 
 /* Test hook: copy one stage tile of problem b out of the workspace after a solve.
- * which: 0 = A~ (16x16, column-major, [A d; 0 1]), 1 = B~, 2 = K~ = [K kff] and 3 = A~ + B~K~ of the
- * last sweep (both row-major).
- * out_host: float[256].  Synchronises the device. */
+ * which: 0 = A~ = [A d; 0 1], 1 = B~, 2 = K~ = [K kff], 3 = A~ + B~K~ (last sweep).
+ * out_host: float[256], the logical 16x16 tile row-major, zero padded.  Synchronises the device. */
 int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
 
 /* Diagnostic builds (-DNMPC_STAMPS) write cycle counts to dev float[B_max][16]: 8 phases

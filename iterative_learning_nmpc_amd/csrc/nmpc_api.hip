@@ -2,6 +2,7 @@
 // Single translation unit: kernels are included below.  Build: csrc/build.sh (hipcc, gfx950).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -69,6 +70,32 @@ int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     return NMPC_OK;
 }
 
+template <class M>
+int read_tile(Handle* h, int b, int k, int which, float* out) {
+    using G = nmpc::TileGeom<M>;
+    const nmpc::WsLayout<M> wl(h->dims.N);
+    const size_t off[4] = {wl.At + (size_t)k * G::A_FLOATS, wl.Bt + (size_t)k * G::B_FLOATS,
+                           wl.Kt + (size_t)k * G::K_FLOATS, wl.Ct + (size_t)k * G::C_FLOATS};
+    const size_t len[4] = {G::A_FLOATS, G::B_FLOATS, G::K_FLOATS, G::C_FLOATS};
+    float img[512];
+    HIP_TRY(h, hipMemcpy(img, h->ws + (size_t)b * wl.stride + off[which], len[which] * sizeof(float),
+                         hipMemcpyDeviceToHost));
+    std::memset(out, 0, 256 * sizeof(float));
+    if (which == 0) {          // A~ : column-major, stride SA, columns 0..nx ; row nx = e_nx
+        for (int c = 0; c <= M::NX; ++c)
+            for (int i = 0; i < M::NX; ++i) out[i * 16 + c] = img[c * G::SA + i];
+        out[M::NX * 16 + M::NX] = 1.0f;
+    } else if (which == 1) {   // B~
+        for (int c = 0; c < M::NU; ++c)
+            for (int i = 0; i < M::NX; ++i) out[i * 16 + c] = img[c * G::SA + i];
+    } else {                   // K~ (nu rows) / Acl~ (nx rows), row-major 16 per row
+        const int rows = which == 2 ? M::NU : M::NX;
+        for (int i = 0; i < rows; ++i)
+            for (int c = 0; c <= M::NX; ++c) out[i * 16 + c] = img[i * 16 + c];
+        if (which == 3) out[M::NX * 16 + M::NX] = 1.0f;
+    }
+    return NMPC_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -226,6 +253,8 @@ int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, in
     std::memcpy(a.W, h->W, sizeof(a.W));
     std::memcpy(a.We, h->We, sizeof(a.We));
     a.reg = h->reg; a.reg_e = h->reg_e;
+    for (int j = 0; j < 16; ++j)
+        a.rs_free[j] = (j < h->nu) ? 1.0f / std::sqrt(h->W[h->nx + j] + h->reg) : 1.0f;
     a.N = h->dims.N; a.B = B;
     a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm; a.line_search = h->line_search;
     a.yref_per_stage = yref_per_stage ? 1 : 0;
@@ -288,11 +317,8 @@ int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host)
         return fail(h, NMPC_E_ARG, "index out of range");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
-    const size_t N = h->dims.N;
-    const size_t off[4] = {0, N, 2 * N, 3 * N + 1};   // tile images lead every problem's workspace
-    const float* src = h->ws + (size_t)b * h->ws_stride + (off[which] + k) * nmpc::TILE;
-    HIP_TRY(h, hipMemcpy(out_host, src, nmpc::TILE * sizeof(float), hipMemcpyDeviceToHost));
-    return NMPC_OK;
+    if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return read_tile<nmpc::DoubleIntegrator>(h, b, k, which, out_host);
+    return read_tile<nmpc::Centroidal>(h, b, k, which, out_host);
 }
 
 }  // extern "C"

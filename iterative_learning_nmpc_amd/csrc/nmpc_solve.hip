@@ -28,6 +28,7 @@ namespace nmpc {
 struct SolveArgs {
     ModelParams mp;
     float W[32];    // stage weights [nx+nu]
+    float rs_free[16];   // 1/sqrt(W_u + reg): row scale of an input that is decoupled at a stage
     float We[16];   // terminal weights [nx]
     float reg, reg_e;
     int N, B;
@@ -48,7 +49,83 @@ struct SolveArgs {
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
-// Workspace of one problem (float offsets): tile images A~[N], B~[N], K~'[N+1], Acl~'[N+1]
+// Compact stage images in the workspace (only what the 16x16 tiles really hold; tile strides are
+// multiples of 128 B so a tile starts on a cache line):
+//   A~ : columns 0..nx (A | d), rows 0..nx-1, column-major, column stride SA = round4(nx) floats
+//        (row nx = [0..0 1] is synthesised at load)
+//   B~ : columns 0..nu-1, rows 0..nx-1, same column stride
+//   K~ : rows 0..nu-1 of [K kff], row-major, 16 floats per row   (the forward sweep reads rows)
+//   Acl~: rows 0..nx-1 of A~ + B~K~, row-major, 16 floats per row
+template <class M>
+struct TileGeom {
+    static constexpr int SA = (M::NX + 3) & ~3;                       // column stride of A~/B~ images
+    static constexpr int RQ = SA / 4;                                 // row quads stored per column
+    static constexpr int A_FLOATS = (((M::NX + 1) * SA) + 31) & ~31;
+    static constexpr int B_FLOATS = ((M::NU * SA) + 31) & ~31;
+    static constexpr int K_FLOATS = ((M::NU * TS) + 31) & ~31;
+    static constexpr int C_FLOATS = ((M::NX * TS) + 31) & ~31;
+};
+
+// Loads of the compact images come in two halves so that a prefetch stays a prefetch: *_raw issues
+// the loads (clamped addresses, no use of the result), *_fix masks the padding when the tile is
+// consumed a stage later.  (Masking at the load would make the wave wait for it on the spot.)
+// accumulator-layout load of a column-major image with NCOL columns (zeros elsewhere)
+template <class M, int NCOL>
+__device__ __forceinline__ f32x4 load_image_raw(const float* __restrict__ img, int lane) {
+    using G = TileGeom<M>;
+    const int q = lane >> 4, c = lane & 15;
+    const bool ok = (q < G::RQ) && (c < NCOL);
+    return *reinterpret_cast<const f32x4*>(img + (ok ? c : 0) * G::SA + 4 * (ok ? q : 0));
+}
+template <class M, int NCOL, bool HOMOGENEOUS>
+__device__ __forceinline__ f32x4 load_image_fix(f32x4 v, int lane) {
+    using G = TileGeom<M>;
+    const int q = lane >> 4, c = lane & 15;
+    const bool ok = (q < G::RQ) && (c < NCOL);
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o[r] = (ok && 4 * q + r < M::NX) ? v[r] : 0.0f;
+        if (HOMOGENEOUS && c == M::NX && 4 * q + r == M::NX) o[r] = 1.0f;   // row nx of A~ = e_nx
+    }
+    return o;
+}
+// accumulator layout of B~' from the B~ image: element (4q+r, c) of B~' = B~[c][4q+r]
+template <class M>
+__device__ __forceinline__ f32x4 load_image_Bt_raw(const float* __restrict__ img, int lane) {
+    using G = TileGeom<M>;
+    const int q = lane >> 4, c = lane & 15;
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 4 * q + r;
+        const bool ok = (col < M::NU) && (c < M::NX);
+        o[r] = img[(ok ? col : 0) * G::SA + (ok ? c : 0)];
+    }
+    return o;
+}
+template <class M>
+__device__ __forceinline__ f32x4 load_image_Bt_fix(f32x4 v, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = ((4 * q + r < M::NU) && (c < M::NX)) ? v[r] : 0.0f;
+    return o;
+}
+// row-major store of the first NROW rows of an accumulator-layout tile, 16 floats per row.
+// Branch-free (the stage body must stay one basic block): rows >= NROW go to `scratch`, an image
+// nobody reads (slot N of the K~/Acl~ arrays).
+template <int NROW>
+__device__ __forceinline__ void store_rows(float* __restrict__ img, float* __restrict__ scratch, int lane, f32x4 v) {
+    const int q = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* dst = (4 * q + r < NROW) ? img + (4 * q + r) * TS + c : scratch + r * TS + c;
+        *dst = v[r];
+    }
+}
+
+// Workspace of one problem (float offsets): stage images A~[N], B~[N], K~[N+1], Acl~[N+1]
 // (the extra slot is scratch for the software pipeline), then what the linearisation hands to the
 // QP kernel: gradients q[N+1][nx], r[N][nu], constraint values c[N][ng], masks, stage costs, and
 // the problem's "finished" flag.
@@ -57,10 +134,10 @@ struct WsLayout {
     size_t At, Bt, Kt, Ct, q, r, c, act, umk, cost, flag, stride;
     __host__ __device__ explicit WsLayout(int N) {
         size_t o = 0;
-        At = o; o += (size_t)N * TILE;
-        Bt = o; o += (size_t)N * TILE;
-        Kt = o; o += (size_t)(N + 1) * TILE;
-        Ct = o; o += (size_t)(N + 1) * TILE;
+        At = o; o += (size_t)N * TileGeom<M>::A_FLOATS;
+        Bt = o; o += (size_t)N * TileGeom<M>::B_FLOATS;
+        Kt = o; o += (size_t)(N + 1) * TileGeom<M>::K_FLOATS;
+        Ct = o; o += (size_t)(N + 1) * TileGeom<M>::C_FLOATS;
         q = o; o += round4((N + 1) * M::NX);
         r = o; o += round4(N * M::NU);
         c = o; o += round4(N * M::NG);
@@ -131,12 +208,12 @@ __device__ __forceinline__ void store_col16(float* tile, int c, const float (&v)
 // Linearisation: thread t <-> (problem b, stage k), k = N is the terminal stage.
 // A thread owns a whole 1 KiB tile, so storing it directly would make every wave store touch 64
 // different tiles with 16 B each.  Columns therefore go through a 4 KiB LDS stage: the block
-// re-distributes one column of 64 stages so that four lanes write the 64 contiguous bytes of a
-// stage's column (16 tiles x 64 B per store instruction instead of 64 x 16 B).
+// re-distributes one column of 64 stages so that the lanes of a quad group write the contiguous
+// bytes of a stage's column (16 tiles per store instruction instead of 64).
 template <class M>
 __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
-    constexpr int NQ = (NX + 1 + 3) / 4;   // float4 per stored column (rows 0..NX)
+    using G = TileGeom<M>;
     __shared__ __attribute__((aligned(16))) float stage_col[64 * 16];
     __shared__ float* tile_of[2][64];       // A~ / B~ tile of each thread's stage (nullptr: none)
     const int N = a.N;
@@ -152,8 +229,8 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     const int ks = stage ? k : 0;
     const float* Xg = a.X + (size_t)b * (N + 1) * NX;
     const float* Ug = a.U + (size_t)b * N * NU;
-    tile_of[0][tid] = stage ? ws + wl.At + (size_t)k * TILE : nullptr;
-    tile_of[1][tid] = stage ? ws + wl.Bt + (size_t)k * TILE : nullptr;
+    tile_of[0][tid] = stage ? ws + wl.At + (size_t)k * G::A_FLOATS : nullptr;
+    tile_of[1][tid] = stage ? ws + wl.Bt + (size_t)k * G::B_FLOATS : nullptr;
     float x[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)(live ? k : 0) * NX + i];
@@ -186,8 +263,8 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int s = (tid >> 2) + 16 * i;
             float* tile = tile_of[which][s];
-            if (tile != nullptr && quad < NQ)
-                *reinterpret_cast<f32x4*>(tile + j * TS + 4 * quad) =
+            if (tile != nullptr && quad < G::RQ)
+                *reinterpret_cast<f32x4*>(tile + j * G::SA + 4 * quad) =
                     *reinterpret_cast<const f32x4*>(stage_col + s * 16 + 4 * quad);
         }
         __syncthreads();
@@ -209,8 +286,7 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(ks + 1) * NX + (i < NX ? i : 0)]
-                            : (i == NX ? 1.0f : 0.0f);
+            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(ks + 1) * NX + (i < NX ? i : 0)] : 0.0f;
         flush(0, NX, v);
     }
     if (!stage) return;
@@ -243,6 +319,7 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
 template <class M>
 __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
+    using G = TileGeom<M>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -318,7 +395,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     SweepLane sl;
     sl.init(conv, lane, NX);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) sl.rs_free[j] = (j < NU) ? __builtin_amdgcn_rsqf(a.W[NX + (j < NU ? j : 0)] + a.reg) : 1.0f;
+    for (int j = 0; j < 16; ++j) sl.rs_free[j] = a.rs_free[j];
     f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
     bool qm[4], rm[4];           // masks: the register takes an element of q / r
 #pragma unroll
@@ -416,9 +493,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                         }
                     }
                 };
-                f32x4 A0 = load_tile(At + (size_t)(N - 1) * TILE, lane);
-                f32x4 B0 = load_tile(Bt + (size_t)(N - 1) * TILE, lane);
-                f32x4 T0 = load_tile_t(Bt + (size_t)(N - 1) * TILE, lane);
+                f32x4 A0 = load_image_fix<M, NX + 1, true>(load_image_raw<M, NX + 1>(At + (size_t)(N - 1) * G::A_FLOATS, lane), lane);
+                f32x4 B0 = load_image_fix<M, NU, false>(load_image_raw<M, NU>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
+                f32x4 T0 = load_image_Bt_fix<M>(load_image_Bt_raw<M>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
                 f32x4 Qt, St, Rt;
                 {
                     f32x4 Gs, Vt;
@@ -435,9 +512,6 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                         }
                     }
                 }
-                // factors of the stage finished last (its K~, Acl~ are formed in the next stage's
-                // shadow); the first stage's shadow writes zeros to the scratch slot N
-                f32x4 Wp = zero4(), Yp = zero4(), Ap = zero4(), Tp = zero4();
                 for (int k = N - 1; k >= 0; --k) {
 #ifdef NMPC_STAMPS
                     sst.t0 = __builtin_readcyclecounter();
@@ -450,17 +524,14 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
 #else
                     const int kn = (k > 0) ? k - 1 : 0;
 #endif
-                    const f32x4 A1 = load_tile(At + (size_t)kn * TILE, lane);
-                    const f32x4 B1 = load_tile(Bt + (size_t)kn * TILE, lane);
-                    const f32x4 T1 = load_tile_t(Bt + (size_t)kn * TILE, lane);
+                    const f32x4 A1 = load_image_raw<M, NX + 1>(At + (size_t)kn * G::A_FLOATS, lane);
+                    const f32x4 B1 = load_image_raw<M, NU>(Bt + (size_t)kn * G::B_FLOATS, lane);
+                    const f32x4 T1 = load_image_Bt_raw<M>(Bt + (size_t)kn * G::B_FLOATS, lane);
                     f32x4 Wk, Yk;
-                    // shadow work of this stage: gain tiles of stage k+1 (slot N is scratch for the
-                    // first stage) and cost tiles of stage k-1
+                    // independent work issued inside this stage: the cost tiles of stage k-1 (operand
+                    // fetch right after this stage's column loads, barrier product in the MFMA slots)
                     struct Shadow {
-                        GainShadow g;
                         f32x4 Gs, Vt, Qn, Sn, Rn;
-                        float *kdst, *cdst;
-                        int lane;
                         // operand fetch for the next stage's cost tiles: issued after this stage's
                         // column loads, so its LDS latency hides behind the elimination
                         const float *qrow, *rrow, *sqrow, *vtrow;   // stage k-1: 16 B of this lane's row quad
@@ -489,8 +560,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                                 Tb = zero4();
                             }
                         }
-                        __device__ __forceinline__ void mfma_k(int i) { g.mfma_k(i); }
-                        __device__ __forceinline__ void mfma_a(int i) { g.mfma_a(i); }
+                        __device__ __forceinline__ void mfma_k(int) {}
+                        __device__ __forceinline__ void mfma_a(int) {}
                         // barrier terms in ONE product: T = Gs'[Gs | vt] holds G'DG in its columns < nu and
                         // G'v in column nx; end() splits it onto R and S~ (the Gauss-Newton contraction)
                         f32x4 Tb;
@@ -506,18 +577,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                                     Sn[r] += hx_col ? Tb[r] : 0.0f;
                                 }
                             }
-#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
-                            store_tile_t(kdst, lane, g.K);
-                            store_tile_t(cdst, lane, g.Acl);
-#else
-                            asm volatile("" ::"v"(g.K), "v"(g.Acl));
-#endif
                         }
                     } sh;
-                    sh.g.init(Wp, Yp, Ap, Tp);
-                    sh.kdst = Kt + (size_t)(k + 1) * TILE;
-                    sh.cdst = Ct + (size_t)(k + 1) * TILE;
-                    sh.lane = lane;
                     {
                         const int kc = k > 0 ? k - 1 : 0;
                         sh.qrow = qv + kc * TS + 4 * q4; sh.rrow = rv + kc * TS + 4 * q4;
@@ -538,15 +599,22 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     else if (M::N_STATIC_MASKS > 3 && cm == M::static_mask(3)) ok = run(std::integral_constant<unsigned, M::static_mask(3)>{});
                     else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
                     qp_ok = ok && qp_ok;
-                    Wp = Wk; Yp = Yk; Ap = A0; Tp = T0;
-                    A0 = A1; B0 = B1; T0 = T1;
+                    {   // gain tiles of this stage: K~ = -W'Y, Acl~ = A~ + B~K~ (read by the forward sweep)
+                        f32x4 Kk, Acl;
+                        gain_tiles(Wk, Yk, A0, T0, Kk, Acl);
+#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
+                        store_rows<NU>(Kt + (size_t)k * G::K_FLOATS, Kt + (size_t)N * G::K_FLOATS, lane, Kk);
+                        store_rows<NX>(Ct + (size_t)k * G::C_FLOATS, Ct + (size_t)N * G::C_FLOATS, lane, Acl);
+#else
+                        asm volatile("" ::"v"(Kk), "v"(Acl));
+#endif
+                    }
+                    A0 = load_image_fix<M, NX + 1, true>(A1, lane);
+                    B0 = load_image_fix<M, NU, false>(B1, lane);
+                    T0 = load_image_Bt_fix<M>(T1, lane);
                     Qt = sh.Qn; St = sh.Sn; Rt = sh.Rn;
                     SST_TILES(5);
                 }
-                f32x4 Kk, Acl;
-                gain_tiles(Wp, Yp, Ap, Tp, Kk, Acl);
-                store_tile_t(Kt, lane, Kk);
-                store_tile_t(Ct, lane, Acl);
             };
             if (use_ipm) sweep(std::true_type{}); else sweep(std::false_type{});
             __threadfence_block();
@@ -567,7 +635,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
             constexpr int FWD_PF = 4, RQ4 = (NX + 1 + 3) / 4;
             const bool is_x = lane < NX, is_u = (lane >= 16 && lane < 16 + NU);
-            const float* rowbase = ((lane < 16) ? Ct : Kt) + ((lane < 32) ? (lane & 15) : 0) * TS;
+            const float* rowbase = (is_x ? Ct : Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS;
+            const size_t rowstep = is_x ? G::C_FLOATS : G::K_FLOATS;
             float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
             const int dstep = (is_x || is_u) ? 1 : 0;
             f32x4 ring[FWD_PF][RQ4];
@@ -576,7 +645,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 const int kk = (j < N) ? j : N - 1;
 #pragma unroll
                 for (int i4 = 0; i4 < RQ4; ++i4)
-                    ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kk * TILE + 4 * i4);
+                    ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kk * rowstep + 4 * i4);
             }
             for (int k0 = 0; k0 < N; k0 += FWD_PF) {
 #pragma unroll
@@ -589,7 +658,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     const int kn = (k + FWD_PF < N) ? k + FWD_PF : N - 1;
 #pragma unroll
                     for (int i4 = 0; i4 < RQ4; ++i4)
-                        ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kn * TILE + 4 * i4);
+                        ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kn * rowstep + 4 * i4);
                     float acc = 0.0f;
 #pragma unroll
                     for (int i = 0; i <= NX; ++i) acc = fmaf(row[i >> 2][i & 3], vs[i], acc);

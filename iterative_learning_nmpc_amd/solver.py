@@ -170,8 +170,7 @@ class BatchedNmpcSolver:
         _lib.check(self.lib.nmpc_debug_read_tile(self._h, b, k, which,
                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))),
                    self._h, "nmpc_debug_read_tile")
-        img = out.reshape(16, 16)
-        return img.T.copy() if which < 2 else img.copy()   # A~,B~ column-major; K~,Acl~ transposed images
+        return out.reshape(16, 16).copy()   # logical (row, col), zero padded
 
     @property
     def workspace_bytes(self) -> int:
