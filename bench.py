@@ -44,6 +44,18 @@ def algorithmic_work(nx, nu, ng, np_, N, n_sweeps):
     return flops, nbytes
 
 
+def host_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(w, n_ipm, sample):
     """The CPU oracle (fp64 restatement; the reference's acados solver is not installable here)
     on all host cores, same workload, bounded sample."""
@@ -52,11 +64,11 @@ def cpu_baseline(w, n_ipm, sample):
     sl = slice(0, sample)
     args = (w.model_id, w.N, w.mp, o.opt(max_sqp_iter=1, n_ipm=n_ipm, yref_per_stage=1, reg=w.meta["reg"], reg_e=w.meta["reg_e"]),
             w.W, w.W_e, w.x0[sl], w.yref[sl], w.yref_e[sl], w.params[sl], w.X[sl], w.U[sl])
-    threads = o.num_threads()
-    o.solve_batch(*args)                       # warm (page in, thread pool)
+    threads = host_cores()
+    o.solve_batch(*args, nthreads=threads)     # warm (page in, thread pool)
     reps, t0 = 0, time.perf_counter()
     while True:
-        o.solve_batch(*args)
+        o.solve_batch(*args, nthreads=threads)
         reps += 1
         if time.perf_counter() - t0 > 10.0 or reps >= 50:
             break
@@ -157,7 +169,7 @@ def main():
                        "global_batch": world * B, "horizon": N, "parallelism": f"dp{world} (independent problems, no collective)"},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "nmpc_solve_kernel<Centroidal>", "kernel_ms": kernel_ms,
+                         "kernel": "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 4 % of the solve call)", "kernel_ms": kernel_ms,
                          "flops_per_solve": flops, "bytes_per_solve": nbytes,
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS},
             "failed_problems": bad,
