@@ -218,10 +218,12 @@ int nmpc_set_ipm(void* handle, float mu0, float sigma, float s_min, float gamma,
 
 int nmpc_shift_warm_start(void* handle, int B, int shift, float* X, float* U, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
-    if (!h || !X || !U) return fail(h, NMPC_E_ARG, "null argument");
+    if (!h) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!X || !U) return fail(h, NMPC_E_ARG, "null argument");
     if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
     if (shift < 0) return fail(h, NMPC_E_ARG, "negative shift");
-    if (shift == 0 || B == 0) return NMPC_OK;
+    if (shift == 0) return NMPC_OK;
     const int N = h->dims.N;
     if (shift > N) shift = N;
     if ((size_t)N * h->nx > 256 * 16 || (size_t)N * h->nu > 256 * 16)
@@ -238,10 +240,10 @@ int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, in
                      float* stats, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;     // an empty batch is a no-op (its tensors have no storage)
     if (!x0 || !yref || !yref_e || !X || !U || (h->np > 0 && !params)) return fail(h, NMPC_E_ARG, "null argument");
     if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
     if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
-    if (B == 0) return NMPC_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->ws_dirty) {
@@ -288,9 +290,9 @@ int nmpc_riccati_batch(void* handle, int Bsz, int nx, int nu, const float* Q, co
 int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, const float* S_nom,
                         float* err, float* weight, float threshold, float ood_weight, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
+    if (B == 0) return NMPC_OK;
     if (!S || !S_nom || !err) return fail(h, NMPC_E_ARG, "null argument");
     if (B < 0 || T < 1 || ns < 2) return fail(h, NMPC_E_ARG, "need B >= 0, T >= 1, ns >= 2");
-    if (B == 0) return NMPC_OK;
     const size_t lds = (size_t)nmpc::TRB * (ns | 1) * sizeof(float);
     if (lds > 64 * 1024) return fail(h, NMPC_E_ARG, "state dimension too large for the staging tile");
     const long long rows = (long long)B * T;
