@@ -83,6 +83,57 @@ def cpu_baseline(w, n_ipm, sample):
                        f"single-thread {single * 1e3:.2f} ms/solve")
 
 
+def rollout_mode(a, world, rank, dev, dist):
+    """BASELINE configs[3] per-GPU slice: B perturbed rollouts + the shared nominal one, each 2 s = 50
+    replans (first one a 15-iteration cold start), tracking errors [B, 50] against the nominal rollout,
+    one all-gather of the errors per learning iteration, OOD weights on every rank."""
+    from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC
+    from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors, learning_update
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    B, T = a.rollouts, 2.0
+    rng = np.random.default_rng(1000 * rank)
+    x0 = np.zeros((B, 12)); x0[:, 2] = 0.3
+    force = rng.uniform(-1, 1, (B, 3)); force /= np.linalg.norm(force, axis=1, keepdims=True) + 1e-6
+    force *= rng.uniform(50, 70, (B, 1))                     # bc_experimental.yaml:32-35
+    force[0] = 0.0                                           # rollout 0 of every rank: the nominal one
+    push = dict(start=0.2, duration=0.3, force=force)
+    mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+    times = []
+    for it in range(a.warmup + a.steps):
+        mpc.reset()
+        mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        S, _ = mpc.open_loop_device(x0, T, push)
+        err = tracking_error(S, S[0].contiguous(), with_weights=False)
+        err_all = all_gather_tracking_errors(err, world * B)
+        ood, weights = learning_update(err_all)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        if it >= a.warmup:
+            times.append(time.perf_counter() - t0)
+    el = float(np.mean(times))
+    if dist:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    n_replans = S.shape[1]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ILC rollouts/sec (2 s centroidal rollouts, 50 replans, device-resident)",
+            "value": world * B / el, "unit": "rollouts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[3] slice: {B} rollouts/GPU x {n_replans} replans, push 50-70 N, "
+                                   "tracking error vs nominal + all-gather of [B,50] errors",
+                       "solves_per_s": world * B * n_replans / el,
+                       "ood_fraction": float(ood.float().mean().item()),
+                       "failed_rollouts": int(mpc.failed.sum().item())}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +143,9 @@ def main():
     ap.add_argument("--ipm", type=int, default=6)
     ap.add_argument("--sqp", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollouts", type=int, default=0,
+                    help="extra mode (not the headline metric): B rollouts per GPU of 2 s (50 replans) fully "
+                         "on the device, tracking error vs the nominal rollout, all-gather over the ranks")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,6 +160,12 @@ def main():
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    if a.rollouts:
+        rollout_mode(a, world, rank, dev, dist)
+        if dist:
+            dist.destroy_process_group()
+        return
 
     B, N = a.batch, 50
     w = wl.centroidal_trot(B=B, N=N, seed=1000 * rank)

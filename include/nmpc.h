@@ -125,6 +125,36 @@ int nmpc_riccati_batch(void *handle, int Bsz, int nx, int nu, const float *Q, co
 int nmpc_tracking_error(void *handle, int B, int T, int ns, const float *S, const float *S_nom,
                         float *err, float *weight, float threshold, float ood_weight, void *stream);
 
+/* Device-resident receding-horizon rollouts of the centroidal model: the reference's simulator-free
+ * LocomotionMPC.open_loop (mpc_controller/mpc.py:416-462) for B rollouts from ONE host call -- per
+ * replanning step: contact window + base references (mpc.py:210-272, contact_planner.py:121-134),
+ * warm-start shift, solve (15 SQP iterations on the first step, mpc.py:464-473), plant = plan,
+ * optional base push, reference integration (mpc.py:204-208).  All rollouts share the gait clock. */
+typedef struct {
+    int n_replans;          /* replanning steps to run                                        */
+    int nodes_per_replan;   /* optimisation nodes between two replans (replanning period / dt) */
+    int replanning_steps;   /* simulation steps between two replans (mpc.py:113)               */
+    int nodes_per_cycle;    /* columns of the contact table                                    */
+    int start_node;         /* optimisation node of the first replan                           */
+    int first_solve;        /* 1: the first replan is a cold start (no warm start, 15 SQP)     */
+    int max_sqp_first;      /* SQP iterations of a cold start (15)                             */
+    float nlp_tol_first;    /* its step tolerance (nlp_tol / 10)                               */
+    float nlp_tol;          /* steady-state step tolerance (<= 0: none)                        */
+    double sim_dt, time_horizon, nom_height, height_offset;
+    float push_start, push_duration;   /* s, relative to the first replan; duration 0: no push */
+} nmpc_rollout_cfg;
+/* gait: dev int8 [4][nodes_per_cycle]; x: dev [B][12] in initial / out final state; v_des, w_des: dev
+ * double [B][3] (commands are kept in fp64 like the reference's, so the integrated reference matches); ref_state: dev double [B][12] in/out (the controller's integrated base reference);
+ * foot_pos: dev [B][4][3]; push_force: dev [B][3] or NULL; phase: host float[n_replans] recorded gait
+ * phase; X, U: dev trajectories in/out (warm start of the next call); S: dev [B][n_replans][19] recorded
+ * state rows [phase, rdot(3), body rates(3), z, yaw, pitch, roll, base_wrt_feet(8)]; failed: dev int [B]
+ * set to 1 if any solve of the rollout returned NaN / QP failure (caller zeroes it).
+ * Needs B <= B_max, N <= 128, model NMPC_MODEL_CENTROIDAL. */
+int nmpc_rollout_batch(void *handle, int B, const nmpc_rollout_cfg *cfg, const signed char *gait, float *x,
+                       const double *v_des, const double *w_des, double *ref_state, const float *foot_pos,
+                       const float *push_force, const float *phase, float *X, float *U, float *S,
+                       int *status, int *failed, void *stream);
+
 /* Test hook: copy one stage tile of problem b out of the workspace after a solve.
  * which: 0 = A~ = [A d; 0 1], 1 = B~, 2 = K~ = [K kff], 3 = A~ + B~K~ (last sweep).
  * out_host: float[256], the logical 16x16 tile row-major, zero padded.  Synchronises the device. */

@@ -30,9 +30,18 @@ SIGNATURES = {
     "nmpc_riccati_batch": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 12),
     "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p]),
+    "nmpc_rollout_batch": (c_int, [c_void_p, c_int, c_void_p] + [c_void_p] * 14),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }
+
+
+class NmpcRolloutCfg(ctypes.Structure):
+    _fields_ = [("n_replans", c_int), ("nodes_per_replan", c_int), ("replanning_steps", c_int),
+                ("nodes_per_cycle", c_int), ("start_node", c_int), ("first_solve", c_int),
+                ("max_sqp_first", c_int), ("nlp_tol_first", c_float), ("nlp_tol", c_float),
+                ("sim_dt", ctypes.c_double), ("time_horizon", ctypes.c_double), ("nom_height", ctypes.c_double),
+                ("height_offset", ctypes.c_double), ("push_start", c_float), ("push_duration", c_float)]
 
 
 class NmpcDims(ctypes.Structure):

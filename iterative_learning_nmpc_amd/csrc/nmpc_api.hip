@@ -9,6 +9,7 @@
 
 #include "nmpc_solve.hip"
 #include "nmpc_aux.hip.inc"
+#include "nmpc_rollout.hip.inc"
 
 namespace {
 
@@ -22,6 +23,7 @@ struct Handle {
     size_t ws_bytes = 0;
     size_t ws_stride = 0;    // floats per problem
     float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
+    float* roll = nullptr;   // rollout problem tensors: x0 alias, yref, yref_e, params (B_max sized)
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
@@ -44,6 +46,24 @@ int fail(Handle* h, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                             \
             return fail(h, NMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// the handle's configuration as kernel arguments (pointers and batch size left to the caller)
+nmpc::SolveArgs base_args(const Handle* h) {
+    nmpc::SolveArgs a{};
+    a.mp = h->mp;
+    std::memcpy(a.W, h->W, sizeof(a.W));
+    std::memcpy(a.We, h->We, sizeof(a.We));
+    a.reg = h->reg; a.reg_e = h->reg_e;
+    for (int j = 0; j < 16; ++j)
+        a.rs_free[j] = (j < h->nu) ? 1.0f / std::sqrt(h->W[h->nx + j] + h->reg) : 1.0f;
+    a.N = h->dims.N;
+    a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm; a.line_search = h->line_search;
+    a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
+    a.gamma = h->gamma; a.tau_min = h->tau_min; a.rho = h->rho;
+    a.ws = h->ws;
+    a.dbg = h->dbg;
+    return a;
+}
 
 template <class M>
 size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
@@ -138,9 +158,14 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
         e = hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes);
     }
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
+    if (e == hipSuccess) {
+        const size_t per = (size_t)dims->N * (nx + nu) + nx + (size_t)(dims->N + 1) * (np > 0 ? np : 1);
+        e = hipMalloc(reinterpret_cast<void**>(&h->roll), (size_t)dims->B_max * per * sizeof(float));
+    }
     if (e != hipSuccess) {
         g_create_error = std::string("nmpc_create: ") + hipGetErrorString(e);
         if (h->ws) (void)hipFree(h->ws);
+        if (h->roll) (void)hipFree(h->roll);
         delete h;
         return NMPC_E_HIP;
     }
@@ -153,6 +178,7 @@ void nmpc_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->roll) (void)hipFree(h->roll);
     delete h;
 }
 
@@ -250,21 +276,11 @@ int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, in
         HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
         h->ws_dirty = false;
     }
-    nmpc::SolveArgs a{};
-    a.mp = h->mp;
-    std::memcpy(a.W, h->W, sizeof(a.W));
-    std::memcpy(a.We, h->We, sizeof(a.We));
-    a.reg = h->reg; a.reg_e = h->reg_e;
-    for (int j = 0; j < 16; ++j)
-        a.rs_free[j] = (j < h->nu) ? 1.0f / std::sqrt(h->W[h->nx + j] + h->reg) : 1.0f;
-    a.N = h->dims.N; a.B = B;
-    a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm; a.line_search = h->line_search;
+    nmpc::SolveArgs a = base_args(h);
+    a.B = B;
     a.yref_per_stage = yref_per_stage ? 1 : 0;
-    a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
-    a.gamma = h->gamma; a.tau_min = h->tau_min; a.rho = h->rho;
     a.x0 = x0; a.yref = yref; a.yref_e = yref_e; a.params = params ? params : x0;
-    a.X = X; a.U = U; a.status = status; a.stats = stats; a.ws = h->ws;
-    a.dbg = h->dbg;
+    a.X = X; a.U = U; a.status = status; a.stats = stats;
     if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return launch_solve<nmpc::DoubleIntegrator>(h, a, st);
     return launch_solve<nmpc::Centroidal>(h, a, st);
 }
@@ -301,6 +317,70 @@ int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, cons
     hipLaunchKernelGGL(nmpc::nmpc_tracking_error_kernel, dim3((unsigned)blocks), dim3(nmpc::TRB), lds,
                        static_cast<hipStream_t>(stream), rows, T, ns, S, S_nom, err, weight, threshold,
                        ood_weight);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const signed char* gait, float* x,
+                       const double* v_des, const double* w_des, double* ref_state, const float* foot_pos,
+                       const float* push_force, const float* phase, float* X, float* U, float* S,
+                       int* status, int* failed, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!cfg || !gait || !x || !v_des || !w_des || !ref_state || !foot_pos || !phase || !X || !U || !S || !status || !failed)
+        return fail(h, NMPC_E_ARG, "null argument");
+    if (h->dims.model_id != NMPC_MODEL_CENTROIDAL) return fail(h, NMPC_E_ARG, "rollouts need the centroidal model");
+    if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (h->dims.N > 128) return fail(h, NMPC_E_ARG, "rollouts need N <= 128");
+    if (cfg->n_replans < 1 || cfg->nodes_per_replan < 1 || cfg->nodes_per_replan > h->dims.N ||
+        cfg->replanning_steps < 1 || cfg->nodes_per_cycle < 1 || cfg->start_node < 0)
+        return fail(h, NMPC_E_ARG, "rollout configuration out of range");
+    if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->ws_dirty) {
+        HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
+        h->ws_dirty = false;
+    }
+    const int N = h->dims.N;
+    float* yref = h->roll;
+    float* yref_e = yref + (size_t)h->dims.B_max * N * 24;
+    float* params = yref_e + (size_t)h->dims.B_max * 12;
+    nmpc::RolloutArgs r{};
+    r.B = B; r.N = N; r.npc = cfg->nodes_per_cycle;
+    r.nodes_per_replan = cfg->nodes_per_replan; r.replanning_steps = cfg->replanning_steps;
+    r.n_replans = cfg->n_replans;
+    r.sim_dt = cfg->sim_dt; r.t_horizon = cfg->time_horizon; r.nom_height = cfg->nom_height;
+    r.height_offset = cfg->height_offset;
+    r.mass = h->mp.mass; r.gz = h->mp.gz;
+    r.gait = gait; r.x = x; r.v_des = v_des; r.w_des = w_des; r.ref_state = ref_state; r.foot_pos = foot_pos;
+    r.push_force = push_force; r.yref = yref; r.yref_e = yref_e; r.params = params;
+    r.X = X; r.U = U; r.S = S; r.status = status; r.failed = failed;
+    nmpc::SolveArgs a = base_args(h);
+    a.B = B; a.yref_per_stage = 1;
+    a.x0 = x; a.yref = yref; a.yref_e = yref_e; a.params = params; a.X = X; a.U = U;
+    a.status = status; a.stats = nullptr;
+    const float dt_replan = (float)(cfg->replanning_steps * cfg->sim_dt);
+    for (int i = 0; i < cfg->n_replans; ++i) {
+        const bool cold = cfg->first_solve && i == 0;
+        r.node = cfg->start_node + i * cfg->nodes_per_replan;
+        r.first = cold ? 1 : 0;
+        r.replan_index = i;
+        r.phase = phase[i];
+        const float t_now = i * dt_replan;
+        r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= cfg->push_start &&
+                     t_now < cfg->push_start + cfg->push_duration) ? dt_replan : 0.0f;
+        hipLaunchKernelGGL(nmpc::nmpc_rollout_prepare_kernel, dim3(B), dim3(64), 0, st, r);
+        if (!cold)
+            hipLaunchKernelGGL(nmpc::nmpc_shift_kernel, dim3(B), dim3(256), 0, st, N, h->nx, h->nu,
+                               cfg->nodes_per_replan, X, U);
+        a.max_sqp = cold ? cfg->max_sqp_first : h->max_sqp;
+        a.nlp_tol = cold ? cfg->nlp_tol_first : cfg->nlp_tol;
+        const int rc = launch_solve<nmpc::Centroidal>(h, a, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nmpc::nmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, r);
+    }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
 }

@@ -128,11 +128,18 @@ class BatchedLocomotionMPC:
                                            self.height_offset)
 
     def increment_base_ref_position(self, n_steps: int = 1) -> None:
-        for b in range(self.batch):
-            R = rpy_to_matrix(self.base_ref_vel_tracking[b, 3:6][::-1])
-            v_glob = np.round(R @ self.v_des[b], 1)
-            self.base_ref_vel_tracking[b, :2] += v_glob[:2] * self.sim_dt * n_steps
-            self.base_ref_vel_tracking[b, 3] += self.w_des[b, 2] * self.sim_dt * n_steps
+        """mpc.py:204-208, once per simulation step, vectorised over the batch."""
+        s = self.base_ref_vel_tracking
+        for _ in range(n_steps):
+            cr, sr = np.cos(s[:, 5]), np.sin(s[:, 5])
+            cp, sp = np.cos(s[:, 4]), np.sin(s[:, 4])
+            cy, sy = np.cos(s[:, 3]), np.sin(s[:, 3])
+            v = self.v_des
+            vx = cy * cp * v[:, 0] + (cy * sp * sr - sy * cr) * v[:, 1] + (cy * sp * cr + sy * sr) * v[:, 2]
+            vy = sy * cp * v[:, 0] + (sy * sp * sr + cy * cr) * v[:, 1] + (sy * sp * cr - cy * sr) * v[:, 2]
+            s[:, 0] += np.round(vx, 1) * self.sim_dt
+            s[:, 1] += np.round(vy, 1) * self.sim_dt
+            s[:, 3] += self.w_des[:, 2] * self.sim_dt
 
     # -- one replanning step --------------------------------------------------------------------
     def build_problem(self, x: np.ndarray):
@@ -194,8 +201,51 @@ class BatchedLocomotionMPC:
             self.sim_step += self.replanning_steps
             self.current_opt_node += self.nodes_per_replan
             self.increment_base_ref_position(self.replanning_steps)
+        self._x_last = x
         S = torch.as_tensor(np.stack(rec, axis=1), dtype=torch.float32).to(self.device).contiguous()
         return S, np.asarray(times)
+
+    def open_loop_device(self, x0: np.ndarray, trajectory_time: float, push: Optional[dict] = None):
+        """`open_loop` with the whole rollout on the device: one C call launches every replanning
+        step (references, shift, solve, plant update) on the stream -- no host round trip per replan.
+        Same return value as `open_loop`; the controller state (X, U, node, reference) advances alike."""
+        import ctypes
+        from . import _lib
+        s, B, dev = self.solver, self.batch, self.device
+        dt_replan = self.replanning_steps * self.sim_dt
+        n_replans = int(np.floor(trajectory_time / dt_replan + 1e-9))
+        if self.foot_pos is None:
+            self.foot_pos = np.asarray(x0)[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]
+        period = self.config_gait.nominal_period
+        times = np.arange(n_replans) * dt_replan
+        phase = np.ascontiguousarray(np.round((times % period) / period, 4), dtype=np.float32)
+        cfg = _lib.NmpcRolloutCfg(
+            n_replans, self.nodes_per_replan, self.replanning_steps, self.contact_planner.nodes_per_cycle,
+            self.current_opt_node, int(self.first_solve), N_SQP_FIRST, self.config_opt.nlp_tol / 10.0,
+            self.config_opt.nlp_tol, self.sim_dt, self.config_opt.time_horizon, self.config_gait.nom_height,
+            self.height_offset, float(push["start"]) if push else 0.0, float(push["duration"]) if push else 0.0)
+        gait = torch.as_tensor(np.ascontiguousarray(self.contact_planner.gait_sequence), dtype=torch.int8).to(dev)
+        x = s.to_device(x0)
+        v_des = torch.as_tensor(self.v_des, dtype=torch.float64).to(dev).contiguous()
+        w_des = torch.as_tensor(self.w_des, dtype=torch.float64).to(dev).contiguous()
+        ref_state = torch.as_tensor(self.base_ref_vel_tracking, dtype=torch.float64).to(dev).contiguous()
+        foot = s.to_device(self.foot_pos.reshape(B, 12))
+        force = s.to_device(np.asarray(push["force"])) if push else None
+        S = torch.empty(B, n_replans, 19, dtype=torch.float32, device=dev)
+        failed = torch.zeros(B, dtype=torch.int32, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(s.lib.nmpc_rollout_batch(
+            s._h, B, ctypes.byref(cfg), p(gait), p(x), p(v_des), p(w_des), p(ref_state), p(foot), p(force),
+            phase.ctypes.data_as(ctypes.c_void_p), p(self.X), p(self.U), p(S), p(self.status), p(failed),
+            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), s._h, "nmpc_rollout_batch")
+        # advance the host-side bookkeeping as open_loop does
+        self.first_solve = False
+        self.sim_step += n_replans * self.replanning_steps
+        self.current_opt_node += n_replans * self.nodes_per_replan
+        s.last_node = self.current_opt_node - self.nodes_per_replan
+        self.base_ref_vel_tracking = ref_state.cpu().numpy()
+        self.x_final, self.failed = x, failed
+        return S, times
 
     def record_state(self, x: np.ndarray, t: float) -> np.ndarray:
         period = self.config_gait.nominal_period

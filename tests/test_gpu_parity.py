@@ -376,3 +376,33 @@ def test_full_size_properties(dev):
         setattr(w2, k, getattr(w2, k)[perm])
     X2, U2, _, _ = _gpu_solve(s, w2)
     assert np.array_equal(X2, X[perm]) and np.array_equal(U2, U[perm])
+
+
+def test_device_rollout_matches_host_driven_rollout(dev):
+    """nmpc_rollout_batch (everything on the device, one host call) against open_loop (host loop that
+    builds references with numpy and calls the same solver): same recorded states, same final state,
+    same integrated reference, incl. a yaw-rate command and a push."""
+    from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC
+    B, T = 9, 0.40
+    rng = np.random.default_rng(3)
+    x0 = np.zeros((B, 12)); x0[:, 2] = 0.3
+    x0[:, :2] = rng.normal(0, 0.03, (B, 2)); x0[:, 3] = rng.normal(0, 0.2, B)
+    force = rng.uniform(-1, 1, (B, 3)) * 50.0; force[0] = 0
+    push = dict(start=0.12, duration=0.08, force=force)
+    out = []
+    for mode in ("host", "device"):
+        mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+        mpc.set_command(np.array([0.25, 0.05, 0.0]), 0.3)
+        mpc.base_ref_vel_tracking[:, :2] = x0[:, :2]
+        mpc.base_ref_vel_tracking[:, 3] = x0[:, 3]
+        roll = mpc.open_loop if mode == "host" else mpc.open_loop_device
+        S, t = roll(x0, T, push)
+        S2, t2 = roll(mpc.x_final.double().cpu().numpy() if mode == "device" else mpc._x_last, 0.12, None)   # continue warm
+        torch.cuda.synchronize()
+        out.append((S.cpu().numpy(), S2.cpu().numpy(), mpc.base_ref_vel_tracking.copy(), mpc.current_opt_node,
+                    mpc.X.cpu().numpy()))
+    (Sh, Sh2, refh, nodeh, Xh), (Sd, Sd2, refd, noded, Xd) = out
+    assert Sh.shape == Sd.shape == (B, 10, 19) and Sd2.shape == (B, 3, 19) and nodeh == noded == 26
+    assert np.allclose(refh, refd, rtol=0, atol=1e-12)
+    assert rel(Sd, Sh) < 2e-5 and rel(Sd2, Sh2) < 2e-5 and rel(Xd, Xh) < 2e-5, (rel(Sd, Sh), rel(Sd2, Sh2), rel(Xd, Xh))
+    assert np.abs(Sd[1:, -1] - Sd[0, -1]).max() > 1e-3          # the pushes did something
