@@ -464,129 +464,90 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     P[r] = v;
                 }
             }
-            // Software-pipelined backward sweep.  The wave is alone on its SIMD at B = 1024, so
-            // nothing else hides latency: stage tiles are prefetched one stage ahead, and the work
-            // that is off the critical path (K~/Acl~ of the previous stage + their stores, cost
-            // tiles of the next stage) is issued in the shadow of the elimination.
+            // Backward sweep.  The wave is alone on its SIMD at B = 1024, so nothing else hides
+            // latency: stage images are prefetched one stage ahead and the cost tiles of the next
+            // stage are built inside the current one.
             auto sweep = [&](auto ipm_tag) {
                 constexpr bool IPM = decltype(ipm_tag)::value;
-                // additive cost tiles of stage kk: Q~ = [Q q; q' 0], S~ = [0 r], R (+ barrier terms)
-                // operands of the additive cost tiles of stage kk: Q~ = [Q q; q' 0], S~ = [0 r], R, and
-                // for the barrier terms Gs = sqrt(D).G, Vt = (v/sqrt(D)) e_nx  (R += Gs'Gs, S~ += Gs'Vt)
-                auto cost_operands = [&](int kk, f32x4& Qt, f32x4& St, f32x4& Rt, f32x4& Gs, f32x4& Vt) {
-                    Rt = Rc;
-                    const f32x4 q4v = *reinterpret_cast<const f32x4*>(qv + kk * TS + 4 * q4);   // q[4q..4q+3]
-                    const f32x4 r4v = *reinterpret_cast<const f32x4*>(rv + kk * TS + 4 * q4);
-                    const float qcv = qv[kk * TS + (c < NX ? c : 0)];                          // q[c]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Qt[r] = Qc[r] + (qm[r] ? (is_hx_col ? q4v[r] : qcv) : 0.0f);
-                        St[r] = rm[r] ? r4v[r] : 0.0f;
-                    }
-                    if constexpr (IPM) {
-                        const f32x4 sq4 = *reinterpret_cast<const f32x4*>(gsq + kk * TS + 4 * q4);
-                        const f32x4 vt4 = *reinterpret_cast<const f32x4*>(gvt + kk * TS + 4 * q4);
+                // The additive cost tiles of a stage (NextCost of backward_stage): Q~ = [Q q; q' 0],
+                // S~ = [0 r], R, and with the barrier Gs = sqrt(D).G, vt = v/sqrt(D):
+                // T = Gs'[Gs | vt] holds G'DG in its columns < nu and G'v in column nx (ONE product, the
+                // Gauss-Newton contraction of the barrier); finish() splits it onto R and S~.
+                struct NextCost {
+                    f32x4 Gs, Vt, Tb, Qn, Sn, Rn;
+                    const float *qrow, *rrow, *sqrow, *vtrow;   // 16 B of this lane's row quad of q, r, sqrt(D), vt
+                    const float* qcol;                          // q[c]
+                    const bool *qm, *rm;
+                    f32x4 Qc, Rc, Gc;
+                    bool hx_col;
+                    __device__ __forceinline__ void fetch() {
+                        Rn = Rc;
+                        const f32x4 q4v = *reinterpret_cast<const f32x4*>(qrow);
+                        const f32x4 r4v = *reinterpret_cast<const f32x4*>(rrow);
+                        const float qcv = *qcol;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            Gs[r] = Gc[r] * sq4[r];                 // rows >= ng: Gc = 0
-                            Vt[r] = is_hx_col ? vt4[r] : 0.0f;
+                            Qn[r] = Qc[r] + (qm[r] ? (hx_col ? q4v[r] : qcv) : 0.0f);
+                            Sn[r] = rm[r] ? r4v[r] : 0.0f;
+                        }
+                        if constexpr (IPM) {
+                            const f32x4 sq4 = *reinterpret_cast<const f32x4*>(sqrow);
+                            const f32x4 vt4 = *reinterpret_cast<const f32x4*>(vtrow);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                Gs[r] = Gc[r] * sq4[r];                  // rows >= ng: Gc = 0
+                                Vt[r] = hx_col ? vt4[r] : Gs[r];         // [Gs | vt]
+                            }
+                            Tb = zero4();
                         }
                     }
+                    __device__ __forceinline__ void mfma(int i) {
+                        if constexpr (IPM) Tb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Tb, 0, 0, 0);
+                    }
+                    __device__ __forceinline__ void finish() {
+                        if constexpr (IPM) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                Rn[r] += hx_col ? 0.0f : Tb[r];     // columns >= nu of Tb are zero
+                                Sn[r] += hx_col ? Tb[r] : 0.0f;
+                            }
+                        }
+                    }
+                };
+                auto next_cost = [&](int kk) {
+                    NextCost nc;
+                    nc.qrow = qv + kk * TS + 4 * q4; nc.rrow = rv + kk * TS + 4 * q4;
+                    nc.sqrow = gsq + kk * TS + 4 * q4; nc.vtrow = gvt + kk * TS + 4 * q4;
+                    nc.qcol = qv + kk * TS + (c < NX ? c : 0);
+                    nc.qm = qm; nc.rm = rm;
+                    nc.Qc = Qc; nc.Rc = Rc; nc.Gc = Gc; nc.hx_col = is_hx_col;
+                    return nc;
                 };
                 f32x4 A0 = load_image_fix<M, NX + 1, true>(load_image_raw<M, NX + 1>(At + (size_t)(N - 1) * G::A_FLOATS, lane), lane);
                 f32x4 B0 = load_image_fix<M, NU, false>(load_image_raw<M, NU>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
                 f32x4 T0 = load_image_Bt_fix<M>(load_image_Bt_raw<M>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
                 f32x4 Qt, St, Rt;
-                {
-                    f32x4 Gs, Vt;
-                    cost_operands(N - 1, Qt, St, Rt, Gs, Vt);
-                    if constexpr (IPM) {
-                        f32x4 GV;
+                {   // prologue: cost tiles of stage N-1
+                    NextCost nc = next_cost(N - 1);
+                    nc.fetch();
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) GV[r] = is_hx_col ? Vt[r] : Gs[r];
-                        const f32x4 T = xty(Gs, GV);   // [G'DG | G'v]: the Gauss-Newton contraction of the barrier
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            Rt[r] += is_hx_col ? 0.0f : T[r];
-                            St[r] += is_hx_col ? T[r] : 0.0f;
-                        }
-                    }
+                    for (int i = 0; i < 4; ++i) nc.mfma(i);
+                    nc.finish();
+                    Qt = nc.Qn; St = nc.Sn; Rt = nc.Rn;
                 }
                 for (int k = N - 1; k >= 0; --k) {
 #ifdef NMPC_STAMPS
                     sst.t0 = __builtin_readcyclecounter();
 #endif
-                    // next stage's tiles: issued first, consumed by the register rotation at the end
+                    // next stage's images: issued first, consumed by the register rotation at the end
                     // of this stage -- by then only this stage's K~/Acl~ stores are younger (vmcnt
                     // retires in order), so neither the loads nor the stores ever stall the sweep
-#ifdef NMPC_EXP_SAMETILE   // timing experiment: every stage re-reads one (cache-resident) tile
-                    const int kn = 0;
-#else
                     const int kn = (k > 0) ? k - 1 : 0;
-#endif
                     const f32x4 A1 = load_image_raw<M, NX + 1>(At + (size_t)kn * G::A_FLOATS, lane);
                     const f32x4 B1 = load_image_raw<M, NU>(Bt + (size_t)kn * G::B_FLOATS, lane);
                     const f32x4 T1 = load_image_Bt_raw<M>(Bt + (size_t)kn * G::B_FLOATS, lane);
                     f32x4 Wk, Yk;
-                    // independent work issued inside this stage: the cost tiles of stage k-1 (operand
-                    // fetch right after this stage's column loads, barrier product in the MFMA slots)
-                    struct Shadow {
-                        f32x4 Gs, Vt, Qn, Sn, Rn;
-                        // operand fetch for the next stage's cost tiles: issued after this stage's
-                        // column loads, so its LDS latency hides behind the elimination
-                        const float *qrow, *rrow, *sqrow, *vtrow;   // stage k-1: 16 B of this lane's row quad
-                        const float* qcol;                          // stage k-1: q[c]
-                        const bool *qm, *rm;
-                        f32x4 Qc, Rc, Gc;
-                        bool hx_col;
-                        __device__ __forceinline__ void begin() {
-                            Rn = Rc;
-                            const f32x4 q4v = *reinterpret_cast<const f32x4*>(qrow);
-                            const f32x4 r4v = *reinterpret_cast<const f32x4*>(rrow);
-                            const float qcv = *qcol;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                Qn[r] = Qc[r] + (qm[r] ? (hx_col ? q4v[r] : qcv) : 0.0f);
-                                Sn[r] = rm[r] ? r4v[r] : 0.0f;
-                            }
-                            if constexpr (IPM) {
-                                const f32x4 sq4 = *reinterpret_cast<const f32x4*>(sqrow);
-                                const f32x4 vt4 = *reinterpret_cast<const f32x4*>(vtrow);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    Gs[r] = Gc[r] * sq4[r];                  // rows >= ng: Gc = 0
-                                    Vt[r] = hx_col ? vt4[r] : Gs[r];         // [Gs | vt]
-                                }
-                                Tb = zero4();
-                            }
-                        }
-                        __device__ __forceinline__ void mfma_k(int) {}
-                        __device__ __forceinline__ void mfma_a(int) {}
-                        // barrier terms in ONE product: T = Gs'[Gs | vt] holds G'DG in its columns < nu and
-                        // G'v in column nx; end() splits it onto R and S~ (the Gauss-Newton contraction)
-                        f32x4 Tb;
-                        __device__ __forceinline__ void mfma_r(int i) {
-                            if constexpr (IPM) Tb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Tb, 0, 0, 0);
-                        }
-                        __device__ __forceinline__ void mfma_s(int) {}
-                        __device__ __forceinline__ void end() {
-                            if constexpr (IPM) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    Rn[r] += hx_col ? 0.0f : Tb[r];     // columns >= nu of Tb are zero
-                                    Sn[r] += hx_col ? Tb[r] : 0.0f;
-                                }
-                            }
-                        }
-                    } sh;
-                    {
-                        const int kc = k > 0 ? k - 1 : 0;
-                        sh.qrow = qv + kc * TS + 4 * q4; sh.rrow = rv + kc * TS + 4 * q4;
-                        sh.sqrow = gsq + kc * TS + 4 * q4; sh.vtrow = gvt + kc * TS + 4 * q4;
-                        sh.qcol = qv + kc * TS + (c < NX ? c : 0);
-                        sh.qm = qm; sh.rm = rm;
-                        sh.Qc = Qc; sh.Rc = Rc; sh.Gc = Gc; sh.hx_col = is_hx_col;
-                    }
+                    NextCost sh = next_cost(kn);
                     const unsigned cm = umask[k];
                     auto run = [&](auto mask_tag) {
                         return backward_stage<NU, decltype(mask_tag)::value>(P, A0, B0, Qt, St, Rt, conv, sl, lane,
@@ -602,12 +563,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     {   // gain tiles of this stage: K~ = -W'Y, Acl~ = A~ + B~K~ (read by the forward sweep)
                         f32x4 Kk, Acl;
                         gain_tiles(Wk, Yk, A0, T0, Kk, Acl);
-#ifndef NMPC_EXP_NOSTORE   // timing experiments only (tools/phase_shares.py)
                         store_rows<NU>(Kt + (size_t)k * G::K_FLOATS, Kt + (size_t)N * G::K_FLOATS, lane, Kk);
                         store_rows<NX>(Ct + (size_t)k * G::C_FLOATS, Ct + (size_t)N * G::C_FLOATS, lane, Acl);
-#else
-                        asm volatile("" ::"v"(Kk), "v"(Acl));
-#endif
                     }
                     A0 = load_image_fix<M, NX + 1, true>(A1, lane);
                     B0 = load_image_fix<M, NU, false>(B1, lane);

@@ -59,17 +59,16 @@ struct SweepLane {
 //   Aa, Ba: A~_k, B~_k.  Qt, St, Rt: additive cost tiles (Q~, S~, R incl. barrier terms).
 //   conv: 3*CTILE floats of LDS.  MASK: compile-time coupling mask of the inputs, or DYNAMIC_MASK
 //   with the run-time mask in `coupled` (branchy fallback).
-//   sh: "shadow" work of the neighbouring stages, independent of this stage's elimination -- the
-//   gain tiles K~/Acl~ of stage k+1 (and their stores) and the cost tiles of stage k-1.  Its 16 MFMAs
-//   and the 8 of the P~ symmetrisation are issued two per pivot inside the LDL' chain (MFMA_SLOTS).
+//   nc: the cost tiles of stage k-1, which do not depend on this stage: fetch() reads their LDS
+//   operands right behind this stage's column loads, mfma(i) is K step i of their barrier product,
+//   finish() folds the product into R and S~.  The wave is alone on its SIMD, so this is the only
+//   latency hiding there is: independent work placed where the stage waits anyway.
 // Outputs (accumulator layout): W = D^-1/2 L^-1, Y = D^-1/2 L^-1 H~ux; K~ = -W'Y is left to the
-// caller (next stage's shadow).  Returns false on a non-positive pivot.
-constexpr int MFMA_SLOTS = 24;   // K(4) H1(4) H2(4) R(4) S(4) interleaved, then Acl(4)
-
-template <int NU, unsigned MASK, class Shadow>
+// caller.  Returns false on a non-positive pivot.
+template <int NU, unsigned MASK, class NextCost>
 __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Qt, f32x4 St, f32x4 Rt,
                                                float* conv, const SweepLane& sl, int lane, unsigned coupled,
-                                               f32x4& Wout, f32x4& Yout, Shadow& sh SST_ARG) {
+                                               f32x4& Wout, f32x4& Yout, NextCost& nc SST_ARG) {
     SST_BEGIN;
     const f32x4 PA = xty(P, Aa);
     const f32x4 PB = xty(P, Ba);
@@ -91,43 +90,23 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
             if (i < NU) col[i] = sl.from_lds ? v[r] : ((i == sl.ident_row) ? 1.0f : 0.0f);
         }
     }
-    sh.begin();
+    nc.fetch();
     SST(1);
     // A~'(P~A~) and its bitwise transpose (P~A~)'A~ (same products, same k order): their mean is
     // exactly symmetric, which keeps P~ symmetric over the whole recursion (the tile algebra
     // uses P~ as its own transpose).
     f32x4 H1 = Qt, H2 = Qt;
-    auto slot = [&](int s) {   // s is a constant after unrolling
-        if (s < 20) {
-            const int i = s / 5, w = s % 5;
-            if (w == 0) sh.mfma_k(i);
-            else if (w == 1) H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aa[i], PA[i], H1, 0, 0, 0);
-            else if (w == 2) H2 = __builtin_amdgcn_mfma_f32_16x16x4f32(PA[i], Aa[i], H2, 0, 0, 0);
-            else if (w == 3) sh.mfma_r(i);
-            else sh.mfma_s(i);
-        } else if (s < MFMA_SLOTS) {
-            sh.mfma_a(s - 20);
-        }
-    };
-    constexpr int PER = (MFMA_SLOTS + NU - 1) / NU;
-    bool ok = true;
-#if !NMPC_INTERLEAVE
 #pragma unroll
-    for (int t = 0; t < MFMA_SLOTS; ++t) slot(t);
-#endif
-#ifndef NMPC_EXP_NOELIM
+    for (int i = 0; i < 4; ++i) {
+        H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aa[i], PA[i], H1, 0, 0, 0);
+        H2 = __builtin_amdgcn_mfma_f32_16x16x4f32(PA[i], Aa[i], H2, 0, 0, 0);
+        nc.mfma(i);
+    }
     float rsf[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) rsf[j] = sl.rs_free[j];
-    ok = ldl_eliminate<NU, MASK>(col, coupled, rsf, [&](int j) {
-#pragma unroll
-        for (int t = 0; t < PER; ++t) slot(j * PER + t);
-    });
-#elif NMPC_INTERLEAVE
-#pragma unroll
-    for (int t = 0; t < MFMA_SLOTS; ++t) slot(t);
-#endif
-    sh.end();
+    const bool ok = ldl_eliminate<NU, MASK>(col, coupled, rsf);
+    nc.finish();
     const f32x4 Hxx = 0.5f * (H1 + H2);
     SST(2);
     wave_sync();
@@ -154,18 +133,11 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     return ok;
 }
 
-// Shadow work with nothing to do but the gain tiles of one finished stage (dense-LQ kernel, epilogue).
-struct GainShadow {
-    f32x4 W, nY, Tp, K, Acl;
-    __device__ __forceinline__ void init(f32x4 Wp, f32x4 Yp, f32x4 Ap, f32x4 Tp_) {
-        W = Wp; nY = -Yp; Tp = Tp_; K = zero4(); Acl = Ap;
-    }
-    __device__ __forceinline__ void begin() {}
-    __device__ __forceinline__ void mfma_k(int i) { K = __builtin_amdgcn_mfma_f32_16x16x4f32(W[i], nY[i], K, 0, 0, 0); }
-    __device__ __forceinline__ void mfma_r(int) {}
-    __device__ __forceinline__ void mfma_s(int) {}
-    __device__ __forceinline__ void mfma_a(int i) { Acl = __builtin_amdgcn_mfma_f32_16x16x4f32(Tp[i], K[i], Acl, 0, 0, 0); }
-    __device__ __forceinline__ void end() {}
+// NextCost of a caller that builds its cost tiles itself (dense-LQ kernel).
+struct NoNextCost {
+    __device__ __forceinline__ void fetch() {}
+    __device__ __forceinline__ void mfma(int) {}
+    __device__ __forceinline__ void finish() {}
 };
 
 // K~ = -W'Y and Acl~ = A~ + B~K~ of a finished stage (Bt = B~').

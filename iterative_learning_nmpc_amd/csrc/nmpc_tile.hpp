@@ -121,21 +121,13 @@ __device__ __forceinline__ f32x4 lds_load_acc(const float* t, int lane) {
 //   MASK != DYNAMIC_MASK: the mask is a compile-time constant; inactive pivots AND inactive rows
 //   vanish from the unrolled code and the elimination is straight-line code.
 //   MASK == DYNAMIC_MASK: run-time mask, one wave-uniform branch per pivot.
-// after(j) is called behind pivot j between two scheduling fences: the caller issues there the
-// MFMAs that are independent of the elimination, so that the matrix pipe works in the shadow of
-// this VALU/readlane chain (an in-order wave overlaps the two only if they alternate in program
-// order; left alone, hipcc clusters the MFMAs in front of the chain).
 constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
-#ifndef NMPC_INTERLEAVE
-#define NMPC_INTERLEAVE 0   // 1: pin two shadow MFMAs behind every pivot; 0: leave placement to hipcc
-#endif
 
 // rs_free[j] = 1/sqrt(pivot) of input j when it is uncoupled: its pivot is then the constant
 // R_jj + reg (nothing of B'PB or of the barrier reaches it), so a static mask needs neither the
 // broadcast nor the v_rsq for it.
-template <int NU, unsigned MASK, class After>
-__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, const float (&rs_free)[NU],
-                                              After&& after) {
+template <int NU, unsigned MASK>
+__device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, const float (&rs_free)[NU]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
@@ -157,11 +149,6 @@ __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled
             }
             col[j] = col[j] * __builtin_amdgcn_rsqf(d);
         }
-#if NMPC_INTERLEAVE
-        __builtin_amdgcn_sched_barrier(0);
-        after(j);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
     return ok;
 }
