@@ -54,29 +54,51 @@ __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 //   A~ : columns 0..nx (A | d), rows 0..nx-1, column-major, column stride SA = round4(nx) floats
 //        (row nx = [0..0 1] is synthesised at load)
 //   B~ : columns 0..nu-1, rows 0..nx-1, same column stride
-//   K~ : rows 0..nu-1 of [K kff], row-major, 16 floats per row   (the forward sweep reads rows)
-//   Acl~: rows 0..nx-1 of A~ + B~K~, row-major, 16 floats per row
+//   K~ : rows 0..round4(nu)-1 of [K kff], row-major, 16 floats per row (the forward sweep reads rows)
+//   Acl~: rows 0..round4(nx)-1 of A~ + B~K~, row-major, 16 floats per row
 template <class M>
 struct TileGeom {
     static constexpr int SA = (M::NX + 3) & ~3;                       // column stride of A~/B~ images
     static constexpr int RQ = SA / 4;                                 // row quads stored per column
+    static constexpr int KQ = (M::NU + 3) / 4;                        // row quads of a K~ image
+    static constexpr int CQ = (M::NX + 3) / 4;                        // row quads of an Acl~ image
     static constexpr int A_FLOATS = (((M::NX + 1) * SA) + 31) & ~31;
     static constexpr int B_FLOATS = ((M::NU * SA) + 31) & ~31;
-    static constexpr int K_FLOATS = ((M::NU * TS) + 31) & ~31;
-    static constexpr int C_FLOATS = ((M::NX * TS) + 31) & ~31;
+    static constexpr int K_FLOATS = ((4 * KQ * TS) + 31) & ~31;
+    static constexpr int C_FLOATS = ((4 * CQ * TS) + 31) & ~31;
 };
 
-// Loads of the compact images come in two halves so that a prefetch stays a prefetch: *_raw issues
-// the loads (clamped addresses, no use of the result), *_fix masks the padding when the tile is
-// consumed a stage later.  (Masking at the load would make the wave wait for it on the spot.)
-// accumulator-layout load of a column-major image with NCOL columns (zeros elsewhere)
-template <class M, int NCOL>
-__device__ __forceinline__ f32x4 load_image_raw(const float* __restrict__ img, int lane) {
+// Per-lane byte offsets into a stage image, computed once per kernel.  Every access of the stage
+// sweeps is  uniform image base + lane offset + immediate  (ld_f32/st_f32): no per-access address
+// arithmetic in the VALU.  Loads come in two halves so that a prefetch stays a prefetch: the raw
+// load is issued a stage ahead (clamped in-bounds addresses), *_fix masks the padding when the tile
+// is consumed.  (Masking at the load would make the wave wait for it on the spot.)
+template <class M>
+struct ImageLane {
     using G = TileGeom<M>;
-    const int q = lane >> 4, c = lane & 15;
-    const bool ok = (q < G::RQ) && (c < NCOL);
-    return *reinterpret_cast<const f32x4*>(img + (ok ? c : 0) * G::SA + 4 * (ok ? q : 0));
-}
+    unsigned a_off, b_off, t_off;   // A~ and B~ (accumulator layout: one 16 B load), B~' (4 dwords)
+    __device__ __forceinline__ void init(int lane) {
+        const int q = lane >> 4, c = lane & 15;
+        const bool oka = (q < G::RQ) && (c < M::NX + 1), okb = (q < G::RQ) && (c < M::NU);
+        a_off = 4u * ((oka ? c : 0) * G::SA + 4 * (oka ? q : 0));
+        b_off = 4u * ((okb ? c : 0) * G::SA + 4 * (okb ? q : 0));
+        // element (4q+r, c) of B~' is B~[c][4q+r]: image column 4q+r, row c
+        t_off = 4u * ((4 * q < M::NU ? 4 * q : 0) * G::SA + (c < M::NX ? c : 0));
+    }
+    __device__ __forceinline__ f32x4 load_A(const float* img) const {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + (size_t)a_off);
+    }
+    __device__ __forceinline__ f32x4 load_B(const float* img) const {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + (size_t)b_off);
+    }
+    __device__ __forceinline__ f32x4 load_Bt(const float* img) const {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ld_f32(img, t_off, 4 * r * G::SA);
+        return o;
+    }
+};
+// accumulator-layout tile of a column-major image with NCOL columns (zeros elsewhere)
 template <class M, int NCOL, bool HOMOGENEOUS>
 __device__ __forceinline__ f32x4 load_image_fix(f32x4 v, int lane) {
     using G = TileGeom<M>;
@@ -90,20 +112,6 @@ __device__ __forceinline__ f32x4 load_image_fix(f32x4 v, int lane) {
     }
     return o;
 }
-// accumulator layout of B~' from the B~ image: element (4q+r, c) of B~' = B~[c][4q+r]
-template <class M>
-__device__ __forceinline__ f32x4 load_image_Bt_raw(const float* __restrict__ img, int lane) {
-    using G = TileGeom<M>;
-    const int q = lane >> 4, c = lane & 15;
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = 4 * q + r;
-        const bool ok = (col < M::NU) && (c < M::NX);
-        o[r] = img[(ok ? col : 0) * G::SA + (ok ? c : 0)];
-    }
-    return o;
-}
 template <class M>
 __device__ __forceinline__ f32x4 load_image_Bt_fix(f32x4 v, int lane) {
     const int q = lane >> 4, c = lane & 15;
@@ -112,18 +120,23 @@ __device__ __forceinline__ f32x4 load_image_Bt_fix(f32x4 v, int lane) {
     for (int r = 0; r < 4; ++r) o[r] = ((4 * q + r < M::NU) && (c < M::NX)) ? v[r] : 0.0f;
     return o;
 }
-// row-major store of the first NROW rows of an accumulator-layout tile, 16 floats per row.
-// Branch-free (the stage body must stay one basic block): rows >= NROW go to `scratch`, an image
-// nobody reads (slot N of the K~/Acl~ arrays).
-template <int NROW>
-__device__ __forceinline__ void store_rows(float* __restrict__ img, float* __restrict__ scratch, int lane, f32x4 v) {
-    const int q = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float* dst = (4 * q + r < NROW) ? img + (4 * q + r) * TS + c : scratch + r * TS + c;
-        *dst = v[r];
+// Row-major store of the first NQ row quads of an accumulator-layout tile, 16 floats per row, into
+// the image of stage k of an image array.  Lanes of the other row quads write to the array's
+// scratch image (slot N) instead, so the store needs no branch.  `off` walks down with the stage.
+struct RowStoreLane {
+    unsigned off, step;
+    __device__ __forceinline__ void init(int lane, int nq, int image_floats, int k_first, int k_scratch) {
+        const int q = lane >> 4, c = lane & 15;
+        const bool valid = q < nq;
+        off = 4u * ((valid ? k_first : k_scratch) * image_floats + (valid ? 4 * q * TS : 0) + c);
+        step = valid ? 4u * image_floats : 0u;
     }
-}
+    __device__ __forceinline__ void store(float* images, f32x4 v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_f32(images, off, 4 * r * TS, v[r]);
+        off -= step;
+    }
+};
 
 // Workspace of one problem (float offsets): stage images A~[N], B~[N], K~[N+1], Acl~[N+1]
 // (the extra slot is scratch for the software pipeline), then what the linearisation hands to the
@@ -191,7 +204,7 @@ struct Lds {
         lv = o;  o += round4(M::NG * NS);
         act = o; o += round4(NS);
         umk = o; o += round4(NS);
-        conv = o; o += 3 * CTILE;
+        conv = o; o += CONV_TILES * CTILE;
         total = o;
     }
 };
@@ -480,19 +493,25 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     const bool *qm, *rm;
                     f32x4 Qc, Rc, Gc;
                     bool hx_col;
+                    f32x4 q4v, r4v, sq4, vt4;
+                    float qcv;
                     __device__ __forceinline__ void fetch() {
+                        q4v = *reinterpret_cast<const f32x4*>(qrow);
+                        r4v = *reinterpret_cast<const f32x4*>(rrow);
+                        qcv = *qcol;
+                        if constexpr (IPM) {
+                            sq4 = *reinterpret_cast<const f32x4*>(sqrow);
+                            vt4 = *reinterpret_cast<const f32x4*>(vtrow);
+                        }
+                    }
+                    __device__ __forceinline__ void build() {
                         Rn = Rc;
-                        const f32x4 q4v = *reinterpret_cast<const f32x4*>(qrow);
-                        const f32x4 r4v = *reinterpret_cast<const f32x4*>(rrow);
-                        const float qcv = *qcol;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             Qn[r] = Qc[r] + (qm[r] ? (hx_col ? q4v[r] : qcv) : 0.0f);
                             Sn[r] = rm[r] ? r4v[r] : 0.0f;
                         }
                         if constexpr (IPM) {
-                            const f32x4 sq4 = *reinterpret_cast<const f32x4*>(sqrow);
-                            const f32x4 vt4 = *reinterpret_cast<const f32x4*>(vtrow);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 Gs[r] = Gc[r] * sq4[r];                  // rows >= ng: Gc = 0
@@ -523,35 +542,42 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     nc.Qc = Qc; nc.Rc = Rc; nc.Gc = Gc; nc.hx_col = is_hx_col;
                     return nc;
                 };
-                f32x4 A0 = load_image_fix<M, NX + 1, true>(load_image_raw<M, NX + 1>(At + (size_t)(N - 1) * G::A_FLOATS, lane), lane);
-                f32x4 B0 = load_image_fix<M, NU, false>(load_image_raw<M, NU>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
-                f32x4 T0 = load_image_Bt_fix<M>(load_image_Bt_raw<M>(Bt + (size_t)(N - 1) * G::B_FLOATS, lane), lane);
+                ImageLane<M> il;
+                il.init(lane);
+                RowStoreLane ks, cs;
+                ks.init(lane, G::KQ, G::K_FLOATS, N - 1, N);
+                cs.init(lane, G::CQ, G::C_FLOATS, N - 1, N);
+                f32x4 A0 = load_image_fix<M, NX + 1, true>(il.load_A(At + (size_t)(N - 1) * G::A_FLOATS), lane);
+                f32x4 B0 = load_image_fix<M, NU, false>(il.load_B(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
+                f32x4 T0 = load_image_Bt_fix<M>(il.load_Bt(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
                 f32x4 Qt, St, Rt;
                 {   // prologue: cost tiles of stage N-1
                     NextCost nc = next_cost(N - 1);
                     nc.fetch();
+                    nc.build();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) nc.mfma(i);
                     nc.finish();
                     Qt = nc.Qn; St = nc.Sn; Rt = nc.Rn;
                 }
+                unsigned cm = umask[N - 1];
                 for (int k = N - 1; k >= 0; --k) {
 #ifdef NMPC_STAMPS
                     sst.t0 = __builtin_readcyclecounter();
 #endif
-                    // next stage's images: issued first, consumed by the register rotation at the end
-                    // of this stage -- by then only this stage's K~/Acl~ stores are younger (vmcnt
-                    // retires in order), so neither the loads nor the stores ever stall the sweep
+                    // next stage's images and coupling mask: issued first, consumed by the register
+                    // rotation at the end of this stage -- by then only this stage's K~/Acl~ stores are
+                    // younger (vmcnt retires in order), so neither the loads nor the stores stall the sweep
                     const int kn = (k > 0) ? k - 1 : 0;
-                    const f32x4 A1 = load_image_raw<M, NX + 1>(At + (size_t)kn * G::A_FLOATS, lane);
-                    const f32x4 B1 = load_image_raw<M, NU>(Bt + (size_t)kn * G::B_FLOATS, lane);
-                    const f32x4 T1 = load_image_Bt_raw<M>(Bt + (size_t)kn * G::B_FLOATS, lane);
-                    f32x4 Wk, Yk;
+                    const f32x4 A1 = il.load_A(At + (size_t)kn * G::A_FLOATS);
+                    const f32x4 B1 = il.load_B(Bt + (size_t)kn * G::B_FLOATS);
+                    const f32x4 T1 = il.load_Bt(Bt + (size_t)kn * G::B_FLOATS);
+                    const unsigned cm_next = umask[kn];
+                    f32x4 Kk, Acl;
                     NextCost sh = next_cost(kn);
-                    const unsigned cm = umask[k];
                     auto run = [&](auto mask_tag) {
-                        return backward_stage<NU, decltype(mask_tag)::value>(P, A0, B0, Qt, St, Rt, conv, sl, lane,
-                                                                             cm, Wk, Yk, sh SST_PASS);
+                        return backward_stage<NU, decltype(mask_tag)::value>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
+                                                                             cm, Kk, Acl, sh SST_PASS);
                     };
                     bool ok;
                     if (cm == M::static_mask(0)) ok = run(std::integral_constant<unsigned, M::static_mask(0)>{});
@@ -560,16 +586,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     else if (M::N_STATIC_MASKS > 3 && cm == M::static_mask(3)) ok = run(std::integral_constant<unsigned, M::static_mask(3)>{});
                     else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
                     qp_ok = ok && qp_ok;
-                    {   // gain tiles of this stage: K~ = -W'Y, Acl~ = A~ + B~K~ (read by the forward sweep)
-                        f32x4 Kk, Acl;
-                        gain_tiles(Wk, Yk, A0, T0, Kk, Acl);
-                        store_rows<NU>(Kt + (size_t)k * G::K_FLOATS, Kt + (size_t)N * G::K_FLOATS, lane, Kk);
-                        store_rows<NX>(Ct + (size_t)k * G::C_FLOATS, Ct + (size_t)N * G::C_FLOATS, lane, Acl);
-                    }
+                    ks.store(Kt, Kk);      // gain tiles of this stage, read by the forward sweep
+                    cs.store(Ct, Acl);
                     A0 = load_image_fix<M, NX + 1, true>(A1, lane);
                     B0 = load_image_fix<M, NU, false>(B1, lane);
                     T0 = load_image_Bt_fix<M>(T1, lane);
                     Qt = sh.Qn; St = sh.Sn; Rt = sh.Rn;
+                    cm = cm_next;
                     SST_TILES(5);
                 }
             };
@@ -592,18 +615,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
             constexpr int FWD_PF = 4, RQ4 = (NX + 1 + 3) / 4;
             const bool is_x = lane < NX, is_u = (lane >= 16 && lane < 16 + NU);
-            const float* rowbase = (is_x ? Ct : Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS;
-            const size_t rowstep = is_x ? G::C_FLOATS : G::K_FLOATS;
+            // row of this lane in the image of stage 0, as a byte offset from the workspace base
+            unsigned rowoff = 4u * (unsigned)((is_x ? wl.Ct : wl.Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS);
+            const unsigned rowstep = 4u * (is_x ? G::C_FLOATS : G::K_FLOATS);
             float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
             const int dstep = (is_x || is_u) ? 1 : 0;
-            f32x4 ring[FWD_PF][RQ4];
-#pragma unroll
-            for (int j = 0; j < FWD_PF; ++j) {
-                const int kk = (j < N) ? j : N - 1;
+            auto load_row = [&](unsigned off, f32x4 (&row)[RQ4]) {
 #pragma unroll
                 for (int i4 = 0; i4 < RQ4; ++i4)
-                    ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kk * rowstep + 4 * i4);
-            }
+                    row[i4] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ws) + (size_t)off + 16 * i4);
+            };
+            f32x4 ring[FWD_PF][RQ4];
+#pragma unroll
+            for (int j = 0; j < FWD_PF; ++j) load_row(rowoff + (unsigned)((j < N) ? j : N - 1) * rowstep, ring[j]);
+            const unsigned rowlast = rowoff + (unsigned)(N - 1) * rowstep;
+            rowoff += FWD_PF * rowstep;        // next row to prefetch
             for (int k0 = 0; k0 < N; k0 += FWD_PF) {
 #pragma unroll
                 for (int j = 0; j < FWD_PF; ++j) {
@@ -612,10 +638,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     f32x4 row[RQ4];
 #pragma unroll
                     for (int i4 = 0; i4 < RQ4; ++i4) row[i4] = ring[j][i4];
-                    const int kn = (k + FWD_PF < N) ? k + FWD_PF : N - 1;
-#pragma unroll
-                    for (int i4 = 0; i4 < RQ4; ++i4)
-                        ring[j][i4] = *reinterpret_cast<const f32x4*>(rowbase + (size_t)kn * rowstep + 4 * i4);
+                    load_row(rowoff < rowlast ? rowoff : rowlast, ring[j]);
+                    rowoff += rowstep;
                     float acc = 0.0f;
 #pragma unroll
                     for (int i = 0; i <= NX; ++i) acc = fmaf(row[i >> 2][i & 3], vs[i], acc);

@@ -26,6 +26,10 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // C + X'Y  (all three in accumulator layout)
 __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y, f32x4 C) {
     C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], C, 0, 0, 0);
@@ -57,6 +61,16 @@ __device__ __forceinline__ float bcast(float v, int src) {
 __device__ __forceinline__ float fast_rcp(float d) {
     float r = __builtin_amdgcn_rcpf(d);
     return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+
+// ---- global access as  uniform base + 32-bit lane offset + immediate  ----------------------------
+// (the addressing mode of global_load/store with an SGPR base: no 64-bit VALU address arithmetic
+// per access; `base` must be wave-uniform, `voff` and `imm` are byte offsets)
+__device__ __forceinline__ float ld_f32(const float* base, unsigned voff, int imm) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)voff + imm);
+}
+__device__ __forceinline__ void st_f32(float* base, unsigned voff, int imm, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (size_t)voff + imm) = v;
 }
 
 // ---- global <-> accumulator layout (tile image is column-major, 1 KiB, 16 B aligned) --------
