@@ -620,34 +620,43 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             const unsigned rowstep = 4u * (is_x ? G::C_FLOATS : G::K_FLOATS);
             float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
             const int dstep = (is_x || is_u) ? 1 : 0;
+            // nx+1 floats of a row: whole quads as 16 B loads, the rest as dwords (a 16 B load with
+            // dead elements lets the allocator reuse them at once -- a wait on the load in flight)
             auto load_row = [&](unsigned off, f32x4 (&row)[RQ4]) {
+                constexpr int FULL = (NX + 1) / 4;
 #pragma unroll
-                for (int i4 = 0; i4 < RQ4; ++i4)
+                for (int i4 = 0; i4 < FULL; ++i4)
                     row[i4] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ws) + (size_t)off + 16 * i4);
+#pragma unroll
+                for (int i = 4 * FULL; i <= NX; ++i) row[i >> 2][i & 3] = ld_f32(ws, off, 4 * i);
             };
             f32x4 ring[FWD_PF][RQ4];
 #pragma unroll
             for (int j = 0; j < FWD_PF; ++j) load_row(rowoff + (unsigned)((j < N) ? j : N - 1) * rowstep, ring[j]);
             const unsigned rowlast = rowoff + (unsigned)(N - 1) * rowstep;
             rowoff += FWD_PF * rowstep;        // next row to prefetch
-            for (int k0 = 0; k0 < N; k0 += FWD_PF) {
+            // one stage: consume a ring slot, then refill it with the row FWD_PF stages ahead (the
+            // refill comes after the last use, so old and new value share registers and the loop
+            // carries no copies -- a copy of fresh load data would put a full wait into every stage)
+            auto fwd_stage = [&](int k, f32x4 (&slot)[RQ4]) {
+                float acc = 0.0f;
 #pragma unroll
-                for (int j = 0; j < FWD_PF; ++j) {
-                    const int k = k0 + j;
-                    if (k >= N) break;
-                    f32x4 row[RQ4];
+                for (int i = 0; i <= NX; ++i) acc = fmaf(slot[i >> 2][i & 3], vs[i], acc);
+                load_row(rowoff < rowlast ? rowoff : rowlast, slot);
+                rowoff += rowstep;
+                dst[k * dstep] = acc;
 #pragma unroll
-                    for (int i4 = 0; i4 < RQ4; ++i4) row[i4] = ring[j][i4];
-                    load_row(rowoff < rowlast ? rowoff : rowlast, ring[j]);
-                    rowoff += rowstep;
-                    float acc = 0.0f;
+                for (int i = 0; i < NX; ++i) vs[i] = bcast(acc, i);
+                __builtin_amdgcn_sched_barrier(0);   // keep each refill inside its own stage
+            };
+            int k0 = 0;
+            for (; k0 + FWD_PF <= N; k0 += FWD_PF) {     // whole groups: one straight-line body
 #pragma unroll
-                    for (int i = 0; i <= NX; ++i) acc = fmaf(row[i >> 2][i & 3], vs[i], acc);
-                    dst[k * dstep] = acc;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) vs[i] = bcast(acc, i);
-                }
+                for (int j = 0; j < FWD_PF; ++j) fwd_stage(k0 + j, ring[j]);
             }
+#pragma unroll
+            for (int j = 0; j < FWD_PF - 1; ++j)          // the last N % FWD_PF stages
+                if (k0 + j < N) fwd_stage(k0 + j, ring[j]);
             wave_sync();
             STAMP(3);
             // -------------------------------------------------------- phase I: IPM update
