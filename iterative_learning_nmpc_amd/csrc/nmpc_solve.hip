@@ -436,6 +436,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
         const int n_sweeps = use_ipm ? a.n_ipm : 1;
         bool qp_ok = true;
         float mu_sum = wave_sum(mu_l);          // sum of s.lam over the active rows
+        const bool one_stage_per_lane = N <= 64;
         for (int ii = 0; ii < n_sweeps; ++ii) {
             float tau = 0.0f;
             if (use_ipm) {
@@ -443,6 +444,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 //   D = lam/s, gsq = sqrt(D), gvt = (tau/s + lam + D c)/sqrt(D)
                 // so that the stage sweep only builds Gs = gsq.G and Vt = gvt.e_nx (no divides there)
                 tau = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
+                // (with N <= 64 the update phase of the previous iteration has already written them)
+                if (ii == 0 || !one_stage_per_lane)
                 for (int k = lane; k < N; k += 64) {
                     const unsigned am = actm[k];
                     float uk[NU], gk[NG];
@@ -561,6 +564,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     Qt = nc.Qn; St = nc.Sn; Rt = nc.Rn;
                 }
                 unsigned cm = umask[N - 1];
+                int lane_zero = 0;
+                asm volatile("" : "+v"(lane_zero));
                 for (int k = N - 1; k >= 0; --k) {
 #ifdef NMPC_STAMPS
                     sst.t0 = __builtin_readcyclecounter();
@@ -572,7 +577,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     const f32x4 A1 = il.load_A(At + (size_t)kn * G::A_FLOATS);
                     const f32x4 B1 = il.load_B(Bt + (size_t)kn * G::B_FLOATS);
                     const f32x4 T1 = il.load_Bt(Bt + (size_t)kn * G::B_FLOATS);
-                    const unsigned cm_next = umask[kn];
+                    // (read through an offset the compiler cannot see is uniform: the value stays in a
+                    // VGPR until the end of the stage instead of being scalarised, and waited for, here)
+                    const unsigned cm_next = umask[kn + lane_zero];
                     f32x4 Kk, Acl;
                     NextCost sh = next_cost(kn);
                     auto run = [&](auto mask_tag) {
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     B0 = load_image_fix<M, NU, false>(B1, lane);
                     T0 = load_image_Bt_fix<M>(T1, lane);
                     Qt = sh.Qn; St = sh.Sn; Rt = sh.Rn;
-                    cm = cm_next;
+                    cm = __builtin_amdgcn_readfirstlane(cm_next);
                     SST_TILES(5);
                 }
             };
@@ -660,8 +667,65 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             wave_sync();
             STAMP(3);
             // -------------------------------------------------------- phase I: IPM update
-            if (use_ipm) {
+            if (use_ipm && one_stage_per_lane) {
+                // Lane = stage, everything of the stage in registers: step direction
+                //   ds = -(G du+ + c) - s ,  dlam = tau/s - lam - (lam/s) ds ,
+                // fraction to the boundary  alpha = min(1, gamma / max(-d./.))  (one division per wave),
+                // update, complementarity sum, and the barrier coefficients of the next iteration.
+                const bool live = lane < N;
+                const int k = live ? lane : 0;
+                float du[NU], g[NG], uk[NU], cc[NG], s[NG], l[NG], ds[NG], dl[NG];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { du[i] = AT(dUp, k, i); uk[i] = AT(Us, k, i); }
+                M::gdot(a.mp, du, g);
+                M::gdot(a.mp, uk, cc);          // c = G u - h at the linearisation point
+                const unsigned am = live ? actm[k] : 0u;
+                float rp = 0.0f, rd = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    cc[j] -= M::h(a.mp, j);
+                    s[j] = AT(sv, k, j); l[j] = AT(lv, k, j);
+                    const float is = fast_rcp(s[j]);
+                    ds[j] = -(g[j] + cc[j]) - s[j];
+                    dl[j] = tau * is - l[j] - l[j] * is * ds[j];
+                    const bool on = (am >> j) & 1u;
+                    rp = on ? fmaxf(rp, -ds[j] * is) : rp;
+                    rd = on ? fmaxf(rd, -dl[j] * __builtin_amdgcn_rcpf(l[j])) : rd;
+                }
+                const float rpm = wave_max(rp), rdm = wave_max(rd);
+                const float ap = rpm > a.gamma ? a.gamma / rpm : 1.0f;
+                const float ad = rdm > a.gamma ? a.gamma / rdm : 1.0f;
+                float m_l = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const bool on = (am >> j) & 1u;
+                    s[j] += on ? ap * ds[j] : 0.0f;
+                    l[j] += on ? ad * dl[j] : 0.0f;
+                    if (live) { AT(sv, k, j) = s[j]; AT(lv, k, j) = l[j]; }
+                    m_l += on ? s[j] * l[j] : 0.0f;
+                }
+                mu_sum = wave_sum(m_l);
+                for (int i = lane; i < NX * NS; i += 64) dX[i] += ap * (dXp[i] - dX[i]);
+                for (int i = lane; i < NU * NS; i += 64) dU[i] += ap * (dUp[i] - dU[i]);
+                if (ii + 1 < n_sweeps && live) {
+                    const float tau_n = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
+                    float sq[NG], vt[NG];
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) {
+                        const bool on = (am >> j) & 1u;
+                        const float is = fast_rcp(s[j]);
+                        const float D = l[j] * is;
+                        const float rs = __builtin_amdgcn_rsqf(D);
+                        sq[j] = on ? D * rs : 0.0f;
+                        vt[j] = on ? (tau_n * is + l[j] + D * cc[j]) * rs : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) { gsq[k * TS + j] = sq[j]; gvt[k * TS + j] = vt[j]; }
+                }
+                wave_sync();
+            } else if (use_ipm) {
                 float ap_l = 1.0f, ad_l = 1.0f;
+                // long horizons (several stages per lane): the same update in two passes.
                 // ds = -(G du+ + c) - s ;  dlam = tau/s - lam - (lam/s) ds   (recomputed in the
                 // second pass rather than kept in runtime-indexed arrays, which would go to scratch)
                 auto step_dir = [&](int k, int j, const float (&g)[NG], const float (&cc)[NG], float& s, float& l, float& dsj, float& dlj) {

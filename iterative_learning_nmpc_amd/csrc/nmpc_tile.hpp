@@ -150,9 +150,12 @@ __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled
         } else {
             const float d = bcast(col[j], j);
             ok = ok && (d > 0.0f);
+            // row j leaves as col[j]/sqrt(d); the multiplier row col[j]/d is that times 1/sqrt(d)
+            // again (one v_rsq per pivot and no reciprocal on the dependent chain)
+            const float rs = __builtin_amdgcn_rsqf(d);
+            col[j] = col[j] * rs;
             if (MASK != DYNAMIC_MASK || ((coupled >> j) & 1u)) {
-                const float rinv = fast_rcp(d);
-                const float w = col[j] * rinv;
+                const float w = col[j] * rs;
 #pragma unroll
                 for (int i = j + 1; i < NU; ++i) {
                     if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
@@ -161,7 +164,6 @@ __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled
                     }
                 }
             }
-            col[j] = col[j] * __builtin_amdgcn_rsqf(d);
         }
     }
     return ok;
