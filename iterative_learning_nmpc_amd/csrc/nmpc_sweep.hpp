@@ -60,7 +60,7 @@ struct SweepLane {
 // The wave is alone on its SIMD, so nothing but the order of this code hides latency:
 //   * chains of dependent MFMAs are issued in pairs (a dependent fp32 MFMA waits 44 cycles, an
 //     independent one issues after 32);
-//   * the eight MFMAs of H~xx sit between the LDS reads (columns, next cost operands) and their
+//   * the MFMAs of A~'P~A~ sit between the LDS reads (columns, next cost operands) and their
 //     first use, fenced so that the scheduler keeps them there.
 // Rows >= NU of Huu, H~ux are exact zeros (B~ has no such columns, R and the barrier no such
 // rows), so W and Y come back from the LDS with zero padding and need no masking.
@@ -96,16 +96,18 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     for (int i4 = 0; i4 < NQ; ++i4) cq[i4] = *reinterpret_cast<const f32x4*>(sl.rd + 4 * i4);
     nc.fetch();
     __builtin_amdgcn_sched_barrier(0);
-    // A~'(P~A~) and its bitwise transpose (P~A~)'A~ (same products, same k order): their mean is
-    // exactly symmetric, which keeps P~ symmetric over the whole recursion (the tile algebra
-    // uses P~ as its own transpose).
-    f32x4 H1 = Qt, H2 = Qt;
+    // H = A~'(P~A~): in exact arithmetic symmetric, in fp32 not quite -- and the tile algebra uses P~
+    // as its own transpose, so the asymmetry would grow along the recursion.  H~xx = (H + H')/2 is
+    // symmetric bit for bit; H' comes back through the sink tile of the LDS (the reads are covered
+    // by the elimination).
+    f32x4 H = Qt;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        H1 = mfma4(Aa[i], PA[i], H1);
-        H2 = mfma4(PA[i], Aa[i], H2);
-    }
+    for (int i = 0; i < 4; ++i) H = mfma4(Aa[i], PA[i], H);
     __builtin_amdgcn_sched_barrier(0);
+    float* Td = conv + 2 * CTILE;
+    lds_store_acc(Td, lane, H);
+    wave_sync();
+    const f32x4 Ht = lds_load_acc_t(Td, lane);
     SST(1);
     float col[NU];
 #pragma unroll
@@ -118,7 +120,7 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     for (int j = 0; j < NU; ++j) rsf[j] = sl.rs_free[j];
     const bool ok = ldl_eliminate<NU, MASK>(col, coupled, rsf);
     nc.finish();
-    const f32x4 Hxx = 0.5f * (H1 + H2);
+    const f32x4 Hxx = 0.5f * (H + Ht);
     SST(2);
     wave_sync();
 #pragma unroll

@@ -122,6 +122,13 @@ __device__ __forceinline__ f32x4 lds_load_acc(const float* t, int lane) {
     return *reinterpret_cast<const f32x4*>(t + c * LDC + 4 * q);
 }
 
+// accumulator layout of the TRANSPOSE of a stored conversion tile: element (c, 4q+r)
+__device__ __forceinline__ f32x4 lds_load_acc_t(const float* t, int lane) {
+    const int q = lane >> 4, c = lane & 15;
+    const float* p = t + (4 * q) * LDC + c;
+    return f32x4{p[0], p[LDC], p[2 * LDC], p[3 * LDC]};
+}
+
 // ---- LDL' elimination in column layout ------------------------------------------------------
 // Lane L < 16 holds column L of Huu (symmetric), lanes 16..31 the columns of [Hux | hu],
 // lanes 32..47 the columns of I.  After the sweep every right-hand-side lane holds
