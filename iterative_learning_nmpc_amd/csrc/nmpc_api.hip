@@ -108,10 +108,12 @@ int read_tile(Handle* h, int b, int k, int which, float* out) {
     } else if (which == 1) {   // B~
         for (int c = 0; c < M::NU; ++c)
             for (int i = 0; i < M::NX; ++i) out[i * 16 + c] = img[c * G::SA + i];
-    } else {                   // K~ (nu rows) / Acl~ (nx rows), row-major 16 per row
+    } else {                   // K~ (nu rows) / Acl~ (nx rows): row-major, 16 floats per row, columns by slot
         const int rows = which == 2 ? M::NU : M::NX;
-        for (int i = 0; i < rows; ++i)
-            for (int c = 0; c <= M::NX; ++c) out[i * 16 + c] = img[i * 16 + c];
+        for (int i = 0; i < rows; ++i) {
+            for (int c = 0; c < M::NX; ++c) out[i * 16 + c] = img[i * 16 + nmpc::slot_of(c)];
+            out[i * 16 + M::NX] = img[i * 16 + nmpc::HS];
+        }
         if (which == 3) out[M::NX * 16 + M::NX] = 1.0f;
     }
     return NMPC_OK;

@@ -49,91 +49,106 @@ struct SolveArgs {
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
-// Compact stage images in the workspace (only what the 16x16 tiles really hold; tile strides are
-// multiples of 128 B so a tile starts on a cache line):
+// Compact stage images in the workspace (tile strides are multiples of 128 B so an image starts
+// on a cache line).  Images hold logical indices; the slot layout of the tiles (nmpc_tile.hpp)
+// exists only in registers and in the column index of the K~/Acl~ rows:
 //   A~ : columns 0..nx (A | d), rows 0..nx-1, column-major, column stride SA = round4(nx) floats
-//        (row nx = [0..0 1] is synthesised at load)
+//        (row HS = e_HS is synthesised at load)
 //   B~ : columns 0..nu-1, rows 0..nx-1, same column stride
-//   K~ : rows 0..round4(nu)-1 of [K kff], row-major, 16 floats per row (the forward sweep reads rows)
-//   Acl~: rows 0..round4(nx)-1 of A~ + B~K~, row-major, 16 floats per row
+//   K~ : rows 0..nu-1 of [K kff], row-major, 16 floats per row indexed by slot (what the forward
+//        sweep multiplies with); rows padded to a multiple of 3
+//   Acl~: rows 0..nx-1 of A~ + B~K~, same format
 template <class M>
 struct TileGeom {
+    static_assert(M::NX <= 12 && M::NU <= 12, "slot layout: at most 12 states and 12 inputs");
     static constexpr int SA = (M::NX + 3) & ~3;                       // column stride of A~/B~ images
     static constexpr int RQ = SA / 4;                                 // row quads stored per column
-    static constexpr int KQ = (M::NU + 3) / 4;                        // row quads of a K~ image
-    static constexpr int CQ = (M::NX + 3) / 4;                        // row quads of an Acl~ image
+    static constexpr int KQ = (M::NU + 2) / 3;                        // row triples of a K~ image
+    static constexpr int CQ = (M::NX + 2) / 3;                        // row triples of an Acl~ image
     static constexpr int A_FLOATS = (((M::NX + 1) * SA) + 31) & ~31;
     static constexpr int B_FLOATS = ((M::NU * SA) + 31) & ~31;
-    static constexpr int K_FLOATS = ((4 * KQ * TS) + 31) & ~31;
-    static constexpr int C_FLOATS = ((4 * CQ * TS) + 31) & ~31;
+    static constexpr int K_FLOATS = ((3 * KQ * TS) + 31) & ~31;
+    static constexpr int C_FLOATS = ((3 * CQ * TS) + 31) & ~31;
 };
+
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
 // Per-lane byte offsets into a stage image, computed once per kernel.  Every access of the stage
 // sweeps is  uniform image base + lane offset + immediate  (ld_f32/st_f32): no per-access address
 // arithmetic in the VALU.  Loads come in two halves so that a prefetch stays a prefetch: the raw
 // load is issued a stage ahead (clamped in-bounds addresses), *_fix masks the padding when the tile
 // is consumed.  (Masking at the load would make the wave wait for it on the spot.)
+// Lane (q, c) of a tile holds row slots 4q..4q+3 = logical rows 3q..3q+2 (+ padding) of column slot c.
 template <class M>
 struct ImageLane {
     using G = TileGeom<M>;
-    unsigned a_off, b_off, t_off;   // A~ and B~ (accumulator layout: one 16 B load), B~' (4 dwords)
+    unsigned a_off, b_off, t_off;   // A~ and B~ (three consecutive rows of a column), B~' (3 dwords)
+    bool a_ok, b_ok, t_ok;
     __device__ __forceinline__ void init(int lane) {
         const int q = lane >> 4, c = lane & 15;
-        const bool oka = (q < G::RQ) && (c < M::NX + 1), okb = (q < G::RQ) && (c < M::NU);
-        a_off = 4u * ((oka ? c : 0) * G::SA + 4 * (oka ? q : 0));
-        b_off = 4u * ((okb ? c : 0) * G::SA + 4 * (okb ? q : 0));
-        // element (4q+r, c) of B~' is B~[c][4q+r]: image column 4q+r, row c
-        t_off = 4u * ((4 * q < M::NU ? 4 * q : 0) * G::SA + (c < M::NX ? c : 0));
+        const int jc = (c == HS) ? M::NX : index_of(c);       // logical column of A~ (d sits at HS)
+        a_ok = (jc >= 0) && (jc <= M::NX) && (3 * q < M::NX);
+        b_ok = (index_of(c) >= 0) && (index_of(c) < M::NU) && (3 * q < M::NX);
+        a_off = 4u * ((a_ok ? jc : 0) * G::SA + (a_ok ? 3 * q : 0));
+        b_off = 4u * ((b_ok ? index_of(c) : 0) * G::SA + (b_ok ? 3 * q : 0));
+        // element (slot(u), slot(x)) of B~' is B~[x][u]: image column u = 3q+r, row x
+        t_ok = (index_of(c) >= 0) && (index_of(c) < M::NX) && (3 * q < M::NU);
+        t_off = 4u * ((t_ok ? 3 * q : 0) * G::SA + (t_ok ? index_of(c) : 0));
     }
-    __device__ __forceinline__ f32x4 load_A(const float* img) const {
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + (size_t)a_off);
+    __device__ __forceinline__ f32x4 load3(const float* img, unsigned off) const {
+        const f32x3u v = *reinterpret_cast<const f32x3u*>(reinterpret_cast<const char*>(img) + (size_t)off);
+        return f32x4{v[0], v[1], v[2], 0.0f};
     }
-    __device__ __forceinline__ f32x4 load_B(const float* img) const {
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + (size_t)b_off);
-    }
+    __device__ __forceinline__ f32x4 load_A(const float* img) const { return load3(img, a_off); }
+    __device__ __forceinline__ f32x4 load_B(const float* img) const { return load3(img, b_off); }
     __device__ __forceinline__ f32x4 load_Bt(const float* img) const {
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = ld_f32(img, t_off, 4 * r * G::SA);
+        for (int r = 0; r < 3; ++r) o[r] = ld_f32(img, t_off, 4 * r * G::SA);
+        o[3] = 0.0f;
+        return o;
+    }
+    // masks of the raw loads: rows/columns beyond the model's dimensions are zero; A~[HS][HS] = 1
+    __device__ __forceinline__ f32x4 fix_A(f32x4 v, int lane) const {
+        const int q = lane >> 4, c = lane & 15;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = (a_ok && 3 * q + r < M::NX) ? v[r] : 0.0f;
+        o[3] = (q == 0 && c == HS) ? 1.0f : 0.0f;
+        return o;
+    }
+    __device__ __forceinline__ f32x4 fix_B(f32x4 v, int lane) const {
+        const int q = lane >> 4;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = (b_ok && 3 * q + r < M::NX) ? v[r] : 0.0f;
+        o[3] = 0.0f;
+        return o;
+    }
+    __device__ __forceinline__ f32x4 fix_Bt(f32x4 v, int lane) const {
+        const int q = lane >> 4;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = (t_ok && 3 * q + r < M::NU) ? v[r] : 0.0f;
+        o[3] = 0.0f;
         return o;
     }
 };
-// accumulator-layout tile of a column-major image with NCOL columns (zeros elsewhere)
-template <class M, int NCOL, bool HOMOGENEOUS>
-__device__ __forceinline__ f32x4 load_image_fix(f32x4 v, int lane) {
-    using G = TileGeom<M>;
-    const int q = lane >> 4, c = lane & 15;
-    const bool ok = (q < G::RQ) && (c < NCOL);
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        o[r] = (ok && 4 * q + r < M::NX) ? v[r] : 0.0f;
-        if (HOMOGENEOUS && c == M::NX && 4 * q + r == M::NX) o[r] = 1.0f;   // row nx of A~ = e_nx
-    }
-    return o;
-}
-template <class M>
-__device__ __forceinline__ f32x4 load_image_Bt_fix(f32x4 v, int lane) {
-    const int q = lane >> 4, c = lane & 15;
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = ((4 * q + r < M::NU) && (c < M::NX)) ? v[r] : 0.0f;
-    return o;
-}
-// Row-major store of the first NQ row quads of an accumulator-layout tile, 16 floats per row, into
-// the image of stage k of an image array.  Lanes of the other row quads write to the array's
-// scratch image (slot N) instead, so the store needs no branch.  `off` walks down with the stage.
+// Row-major store of the logical rows of an accumulator-layout tile (registers 0..2 of the first NQ
+// quads), 16 floats per row, into the image of stage k of an image array.  Lanes of the other quads
+// write to the array's scratch image (slot N) instead, so the store needs no branch.  `off` walks
+// down with the stage.
 struct RowStoreLane {
     unsigned off, step;
     __device__ __forceinline__ void init(int lane, int nq, int image_floats, int k_first, int k_scratch) {
         const int q = lane >> 4, c = lane & 15;
         const bool valid = q < nq;
-        off = 4u * ((valid ? k_first : k_scratch) * image_floats + (valid ? 4 * q * TS : 0) + c);
+        off = 4u * ((valid ? k_first : k_scratch) * image_floats + (valid ? 3 * q * TS : 0) + c);
         step = valid ? 4u * image_floats : 0u;
     }
     __device__ __forceinline__ void store(float* images, f32x4 v) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st_f32(images, off, 4 * r * TS, v[r]);
+        for (int r = 0; r < 3; ++r) st_f32(images, off, 4 * r * TS, v[r]);
         off -= step;
     }
 };
@@ -372,12 +387,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     for (int e = lane; e < (N + 1) * NX; e += 64) {
         const int k = e / NX;
         AT(Xs, k, e - k * NX) = Xg[e];
-        qv[k * TS + (e - k * NX)] = ws[wl.q + e];
+        qv[k * TS + slot_of(e - k * NX)] = ws[wl.q + e];     // sweep operands are indexed by slot
     }
     for (int e = lane; e < N * NU; e += 64) {
         const int k = e / NU;
         AT(Us, k, e - k * NU) = Ug[e];
-        rv[k * TS + (e - k * NU)] = ws[wl.r + e];
+        rv[k * TS + slot_of(e - k * NU)] = ws[wl.r + e];
     }
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
@@ -398,29 +413,33 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             mu_l += a.mu0 * (float)__popc(am);      // s * (mu0 / s) per active row
         }
     }
-    // per-lane weights of "its" column
-    const float wq_c = (c < NX) ? a.W[c] + a.reg : 0.0f;
-    const float wr_c = (c < NU) ? a.W[NX + (c < NU ? c : 0)] + a.reg : 0.0f;
-    const float we_c = (c < NX) ? a.We[c < NX ? c : 0] + a.reg_e : 0.0f;
+    // per-lane weights of "its" column (slot layout: column slot c holds logical index ic, HS the
+    // homogeneous coordinate)
+    const int ic = index_of(c);
+    const bool c_is_x = ic >= 0 && ic < NX, c_is_u = ic >= 0 && ic < NU;
+    const float wq_c = c_is_x ? a.W[c_is_x ? ic : 0] + a.reg : 0.0f;
+    const float wr_c = c_is_u ? a.W[NX + (c_is_u ? ic : 0)] + a.reg : 0.0f;
+    const float we_c = c_is_x ? a.We[c_is_x ? ic : 0] + a.reg_e : 0.0f;
     // per-lane constants of the stage sweeps: which element of q / r / sqrt(D) / v each of the
     // lane's four tile registers takes (a clamped LDS feature index and a 0/1 mask), so that the
     // cost tiles of a stage are built with unconditional loads and selects (no branches)
     SweepLane sl;
-    sl.init(conv, lane, NX);
+    sl.init(conv, lane, HS);
 #pragma unroll
     for (int j = 0; j < 16; ++j) sl.rs_free[j] = a.rs_free[j];
     f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
     bool qm[4], rm[4];           // masks: the register takes an element of q / r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 4 * q4 + r;
-        Qc[r] = (row == c && row < NX) ? wq_c : 0.0f;
-        Rc[r] = (row == c && row < NU) ? wr_c : 0.0f;
-        qm[r] = (c == NX && row < NX) || (row == NX && c < NX);
-        rm[r] = (c == NX && row < NU);
-        Gc[r] = (row < NG && c < NU) ? M::G(a.mp, row < NG ? row : 0, c) : 0.0f;
+        const int row = 4 * q4 + r, ir = index_of(row);      // row slot and its logical index
+        const bool r_is_x = ir >= 0 && ir < NX, r_is_u = ir >= 0 && ir < NU;
+        Qc[r] = (row == c && r_is_x) ? wq_c : 0.0f;
+        Rc[r] = (row == c && r_is_u) ? wr_c : 0.0f;
+        qm[r] = (c == HS && r_is_x) || (row == HS && c_is_x);
+        rm[r] = (c == HS && r_is_u);
+        Gc[r] = (row < NG && c_is_u) ? M::G(a.mp, row < NG ? row : 0, c_is_u ? ic : 0) : 0.0f;   // rows: constraints
     }
-    const bool is_hx_col = (c == NX);
+    const bool is_hx_col = (c == HS);
     wave_sync();
 
     int status = NMPC_STATUS_MAXITER;
@@ -469,14 +488,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             // -------------------------------------------------------- phase R: backward sweep
             f32x4 P;
             {   // terminal: P~ = [diag(We)+reg_e, q_N; q_N', 0]
-                const float qc = (c < NX) ? qv[N * TS + (c < NX ? c : 0)] : 0.0f;
+                const float qc = c_is_x ? qv[N * TS + c] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q4 + r;
+                    const int row = 4 * q4 + r, ir = index_of(row);
+                    const bool r_is_x = ir >= 0 && ir < NX;
                     float v = 0.0f;
-                    if (row == c && row < NX) v = we_c;
-                    if (c == NX && row < NX) v = qv[N * TS + (row < NX ? row : 0)];
-                    if (row == NX && c < NX) v = qc;
+                    if (row == c && r_is_x) v = we_c;
+                    if (c == HS && r_is_x) v = qv[N * TS + row];
+                    if (row == HS && c_is_x) v = qc;
                     P[r] = v;
                 }
             }
@@ -492,7 +512,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 struct NextCost {
                     f32x4 Gs, Vt, Tb, Qn, Sn, Rn;
                     const float *qrow, *rrow, *sqrow, *vtrow;   // 16 B of this lane's row quad of q, r, sqrt(D), vt
-                    const float* qcol;                          // q[c]
+                    const float* qcol;                          // q at this lane's column slot
                     const bool *qm, *rm;
                     f32x4 Qc, Rc, Gc;
                     bool hx_col;
@@ -540,7 +560,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     NextCost nc;
                     nc.qrow = qv + kk * TS + 4 * q4; nc.rrow = rv + kk * TS + 4 * q4;
                     nc.sqrow = gsq + kk * TS + 4 * q4; nc.vtrow = gvt + kk * TS + 4 * q4;
-                    nc.qcol = qv + kk * TS + (c < NX ? c : 0);
+                    nc.qcol = qv + kk * TS + c;
                     nc.qm = qm; nc.rm = rm;
                     nc.Qc = Qc; nc.Rc = Rc; nc.Gc = Gc; nc.hx_col = is_hx_col;
                     return nc;
@@ -550,9 +570,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 RowStoreLane ks, cs;
                 ks.init(lane, G::KQ, G::K_FLOATS, N - 1, N);
                 cs.init(lane, G::CQ, G::C_FLOATS, N - 1, N);
-                f32x4 A0 = load_image_fix<M, NX + 1, true>(il.load_A(At + (size_t)(N - 1) * G::A_FLOATS), lane);
-                f32x4 B0 = load_image_fix<M, NU, false>(il.load_B(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
-                f32x4 T0 = load_image_Bt_fix<M>(il.load_Bt(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
+                f32x4 A0 = il.fix_A(il.load_A(At + (size_t)(N - 1) * G::A_FLOATS), lane);
+                f32x4 B0 = il.fix_B(il.load_B(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
+                f32x4 T0 = il.fix_Bt(il.load_Bt(Bt + (size_t)(N - 1) * G::B_FLOATS), lane);
                 f32x4 Qt, St, Rt;
                 {   // prologue: cost tiles of stage N-1
                     NextCost nc = next_cost(N - 1);
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     f32x4 Kk, Acl;
                     NextCost sh = next_cost(kn);
                     auto run = [&](auto mask_tag) {
-                        return backward_stage<NU, decltype(mask_tag)::value>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
+                        return backward_stage<NU, decltype(mask_tag)::value, true>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
                                                                              cm, Kk, Acl, sh SST_PASS);
                     };
                     bool ok;
@@ -595,9 +615,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     qp_ok = ok && qp_ok;
                     ks.store(Kt, Kk);      // gain tiles of this stage, read by the forward sweep
                     cs.store(Ct, Acl);
-                    A0 = load_image_fix<M, NX + 1, true>(A1, lane);
-                    B0 = load_image_fix<M, NU, false>(B1, lane);
-                    T0 = load_image_Bt_fix<M>(T1, lane);
+                    A0 = il.fix_A(A1, lane);
+                    B0 = il.fix_B(B1, lane);
+                    T0 = il.fix_Bt(T1, lane);
                     Qt = sh.Qn; St = sh.Sn; Rt = sh.Rn;
                     cm = __builtin_amdgcn_readfirstlane(cm_next);
                     SST_TILES(5);
@@ -608,34 +628,34 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             wave_sync();
             STAMP(2);
             // -------------------------------------------------------- phase F: forward sweep
-            // dx~+ = Acl~ dx~ , du = K~ dx~ as ONE row-per-lane mat-vec: lane L < 16 holds row L of
-            // Acl~ (the stored image is row-major), lane 16+j row j of K~; dx~ is wave-uniform (SGPRs,
-            // refreshed by v_readlane).  13 FMAs + 13 readlanes per stage -- fp32 MFMA shares the
-            // VALU's FMA pipes (no overlap for one wave), so the 16-column MFMA mat-vec cost 8x32 cycles.
+            // dx~+ = Acl~ dx~ , du = K~ dx~ as ONE row-per-lane mat-vec: lane i < nx holds row i of
+            // Acl~ (the stored image is row-major, columns by slot), lane 16+j row j of K~; dx~ is
+            // wave-uniform (SGPRs, refreshed by v_readlane).  13 FMAs + 12 readlanes per stage -- fp32
+            // MFMA and VALU do not overlap on a SIMD, so the 16-column MFMA mat-vec cost 8x32 cycles.
             // Rows are prefetched FWD_PF stages ahead (a stage is shorter than an L2 miss).
             float* oX = use_ipm ? dXp : dX;
             float* oU = use_ipm ? dUp : dU;
-            float vs[NX + 1];
+            float vs[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) vs[i] = x0[i] - AT(Xs, 0, i);
-            vs[NX] = 1.0f;
             if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
-            constexpr int FWD_PF = 4, RQ4 = (NX + 1 + 3) / 4;
+            constexpr int FWD_PF = 4, RQ4 = slot_of(NX - 1) / 4 + 1;
             const bool is_x = lane < NX, is_u = (lane >= 16 && lane < 16 + NU);
             // row of this lane in the image of stage 0, as a byte offset from the workspace base
             unsigned rowoff = 4u * (unsigned)((is_x ? wl.Ct : wl.Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS);
             const unsigned rowstep = 4u * (is_x ? G::C_FLOATS : G::K_FLOATS);
             float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
             const int dstep = (is_x || is_u) ? 1 : 0;
-            // nx+1 floats of a row: whole quads as 16 B loads, the rest as dwords (a 16 B load with
-            // dead elements lets the allocator reuse them at once -- a wait on the load in flight)
+            // the used floats of a row: quad 0 (three states and the homogeneous slot) as a 16 B load,
+            // the other quads as 12 B loads (a load with dead elements lets the allocator reuse them at
+            // once -- which means a wait on the load in flight)
             auto load_row = [&](unsigned off, f32x4 (&row)[RQ4]) {
-                constexpr int FULL = (NX + 1) / 4;
+                row[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ws) + (size_t)off);
 #pragma unroll
-                for (int i4 = 0; i4 < FULL; ++i4)
-                    row[i4] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ws) + (size_t)off + 16 * i4);
-#pragma unroll
-                for (int i = 4 * FULL; i <= NX; ++i) row[i >> 2][i & 3] = ld_f32(ws, off, 4 * i);
+                for (int g = 1; g < RQ4; ++g) {
+                    const f32x3u v = *reinterpret_cast<const f32x3u*>(reinterpret_cast<const char*>(ws) + (size_t)off + 16 * g);
+                    row[g] = f32x4{v[0], v[1], v[2], 0.0f};
+                }
             };
             f32x4 ring[FWD_PF][RQ4];
 #pragma unroll
@@ -646,9 +666,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             // refill comes after the last use, so old and new value share registers and the loop
             // carries no copies -- a copy of fresh load data would put a full wait into every stage)
             auto fwd_stage = [&](int k, f32x4 (&slot)[RQ4]) {
-                float acc = 0.0f;
+                float acc = slot[0][HS];          // times dx~[HS] = 1
 #pragma unroll
-                for (int i = 0; i <= NX; ++i) acc = fmaf(slot[i >> 2][i & 3], vs[i], acc);
+                for (int i = 0; i < NX; ++i) acc = fmaf(slot[slot_of(i) >> 2][slot_of(i) & 3], vs[i], acc);
                 load_row(rowoff < rowlast ? rowoff : rowlast, slot);
                 rowoff += rowstep;
                 dst[k * dstep] = acc;

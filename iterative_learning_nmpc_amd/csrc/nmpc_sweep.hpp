@@ -34,6 +34,7 @@ struct SweepLane {
     float* wb;        // write-back column of the eliminated system (groups 0/3 write to the sink Td)
     const float* rd;  // column this lane eliminates: Huu | H~ux | I | I
     bool corner[4];   // true at the (hx,hx) corner of a tile
+    float hs_col;     // 1 in the lanes of the homogeneous column (slot layout), else 0
     float rs_free[16]; // 1/sqrt(R_jj + reg): scale of an uncoupled input's row (wave-uniform)
     // fills the identity tile as well: the caller orders it (wave_sync) before the first stage
     __device__ __forceinline__ void init(float* conv, int lane, int hx) {
@@ -44,16 +45,32 @@ struct SweepLane {
         float* Ti = conv + 3 * CTILE;
         wb = ((t == 1) ? T1 : (t == 2) ? T0 : Td) + c * LDC;
         rd = ((t == 0) ? T0 : (t == 1) ? T1 : Ti) + c * LDC;
+        hs_col = (c == HS) ? 1.0f : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) corner[r] = (c == hx && 4 * t + r == hx);
         for (int i = lane; i < CTILE; i += 64) Ti[i] = (i % LDC == i / LDC) ? 1.0f : 0.0f;
     }
 };
 
+// C + X'Y over the contraction steps 0..STEPS-1, split over two accumulators (see xty2)
+template <int STEPS>
+__device__ __forceinline__ void xty_pair(f32x4 X0, f32x4 Y0, f32x4& C0, f32x4 X1, f32x4 Y1, f32x4& C1) {
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        C0 = mfma4(X0[i], Y0[i], C0);
+        C1 = mfma4(X1[i], Y1[i], C1);
+    }
+}
+
 // One backward stage on the critical path:  P~_{k+1} -> P~_k, and the gain tiles of stage k.
 //   Aa, Ba, Bt: A~_k, B~_k, B~_k'.  Qt, St, Rt: additive cost tiles (Q~, S~, R incl. barrier terms).
 //   conv: CONV_TILES*CTILE floats of LDS.  MASK: compile-time coupling mask of the inputs, or
 //   DYNAMIC_MASK with the run-time mask in `coupled` (branchy fallback).
+//   SLOT3: the tiles are in the slot layout (nmpc_tile.hpp) with the homogeneous coordinate at HS:
+//   every product contracts over three steps; the one row the fourth step would add (row HS of
+//   A~ = e_HS) is patched in with VALU adds.  Without it (dense-LQ entry) rows and columns are in
+//   natural order and products take four steps.
+//   NU counts logical inputs; column j of the elimination sits in lane slot_of(j) under SLOT3.
 //   nc: the cost tiles of stage k-1, which do not depend on this stage: fetch() issues their LDS
 //   reads, build() forms the operands, mfma(i) is K step i of their barrier product, finish() folds
 //   the product into R and S~.
@@ -62,35 +79,29 @@ struct SweepLane {
 //     independent one issues after 32);
 //   * the MFMAs of A~'P~A~ sit between the LDS reads (columns, next cost operands) and their
 //     first use, fenced so that the scheduler keeps them there.
-// Rows >= NU of Huu, H~ux are exact zeros (B~ has no such columns, R and the barrier no such
+// Padding rows of Huu, H~ux are exact zeros (B~ has no such columns, R and the barrier no such
 // rows), so W and Y come back from the LDS with zero padding and need no masking.
 // Outputs (accumulator layout): K~ = -W'Y, Acl~ = A~ + B~K~  with  W = D^-1/2 L^-1,
 // Y = D^-1/2 L^-1 H~ux.  Returns false on a non-positive pivot.
-template <int NU, unsigned MASK, class NextCost>
+template <int NU, unsigned MASK, bool SLOT3, class NextCost>
 __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Bt, f32x4 Qt, f32x4 St,
                                                f32x4 Rt, float* conv, const SweepLane& sl, int lane,
                                                unsigned coupled, f32x4& Kout, f32x4& Aclout,
                                                NextCost& nc SST_ARG) {
+    constexpr int STEPS = SLOT3 ? 3 : 4;
     SST_BEGIN;
     f32x4 PA = zero4(), PB = zero4();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        PA = mfma4(P[i], Aa[i], PA);
-        PB = mfma4(P[i], Ba[i], PB);
-    }
+    xty_pair<STEPS>(P, Aa, PA, P, Ba, PB);
+    if constexpr (SLOT3) PA += sl.hs_col * P;        // row HS of A~ is e_HS: P~A~[:, HS] += P~[HS, :]' (P~ symmetric)
     f32x4 Hux = St, Huu = Rt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        Hux = mfma4(Ba[i], PA[i], Hux);
-        Huu = mfma4(Ba[i], PB[i], Huu);
-    }
+    xty_pair<STEPS>(Ba, PA, Hux, Ba, PB, Huu);       // row HS of B~ is zero
     SST(0);
     lds_store_acc(conv, lane, Huu);
     lds_store_acc(conv + CTILE, lane, Hux);
     wave_sync();
 
     // column layout: lane L -> column (L&15) of tile (L>>4): Huu | H~ux | I | I
-    constexpr int NQ = (NU + 3) / 4;
+    constexpr int NQ = SLOT3 ? slot_of(NU - 1) / 4 + 1 : (NU + 3) / 4;
     f32x4 cq[NQ];
 #pragma unroll
     for (int i4 = 0; i4 < NQ; ++i4) cq[i4] = *reinterpret_cast<const f32x4*>(sl.rd + 4 * i4);
@@ -102,7 +113,8 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     // by the elimination).
     f32x4 H = Qt;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) H = mfma4(Aa[i], PA[i], H);
+    for (int i = 0; i < STEPS; ++i) H = mfma4(Aa[i], PA[i], H);
+    if constexpr (SLOT3) H[3] += PA[3];              // row HS of A~: H[HS, :] += (P~A~)[HS, :]
     __builtin_amdgcn_sched_barrier(0);
     float* Td = conv + 2 * CTILE;
     lds_store_acc(Td, lane, H);
@@ -111,14 +123,14 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     SST(1);
     float col[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) col[i] = cq[i >> 2][i & 3];
+    for (int i = 0; i < NU; ++i) col[i] = SLOT3 ? cq[i / 3][i % 3] : cq[i >> 2][i & 3];
     nc.build();
 #pragma unroll
     for (int i = 0; i < 4; ++i) nc.mfma(i);
     float rsf[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) rsf[j] = sl.rs_free[j];
-    const bool ok = ldl_eliminate<NU, MASK>(col, coupled, rsf);
+    const bool ok = ldl_eliminate<NU, MASK, SLOT3>(col, coupled, rsf);
     nc.finish();
     const f32x4 Hxx = 0.5f * (H + Ht);
     SST(2);
@@ -127,7 +139,11 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     for (int i4 = 0; i4 < NQ; ++i4) {
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (4 * i4 + r < NU) ? col[(4 * i4 + r < NU) ? 4 * i4 + r : 0] : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+            const int i = SLOT3 ? 3 * i4 + r : 4 * i4 + r;
+            const bool used = (i < NU) && !(SLOT3 && r == 3);
+            v[r] = used ? col[used ? i : 0] : 0.0f;
+        }
         *reinterpret_cast<f32x4*>(sl.wb + 4 * i4) = v;
     }
     wave_sync();
@@ -143,10 +159,10 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     K = mfma4(W[0], nY[0], K);
     Pa = mfma4(nY[2], Y[2], Pa);
     K = mfma4(W[1], nY[1], K);
-    Pb = mfma4(nY[3], Y[3], Pb);
+    if constexpr (!SLOT3) Pb = mfma4(nY[3], Y[3], Pb);
     K = mfma4(W[2], nY[2], K);
     f32x4 Pn = Pa + Pb;
-    K = mfma4(W[3], nY[3], K);
+    if constexpr (!SLOT3) K = mfma4(W[3], nY[3], K);
     // the constant term of the cost-to-go (corner hx,hx) feeds nothing: keep it at zero
 #pragma unroll
     for (int r = 0; r < 4; ++r) Pn[r] = sl.corner[r] ? 0.0f : Pn[r];
@@ -156,7 +172,7 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     Ca = mfma4(Bt[0], K[0], Ca);
     Cb = mfma4(Bt[1], K[1], Cb);
     Ca = mfma4(Bt[2], K[2], Ca);
-    Cb = mfma4(Bt[3], K[3], Cb);
+    if constexpr (!SLOT3) Cb = mfma4(Bt[3], K[3], Cb);
     Kout = K;
     Aclout = Ca + Cb;
     return ok;

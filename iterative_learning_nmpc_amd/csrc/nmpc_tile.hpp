@@ -22,6 +22,17 @@ constexpr int LDC = 20;       // LDS column stride (floats) of a conversion tile
                               // ds_read_b128 of 16 different columns conflict-free
 constexpr int CTILE = TS * LDC;
 
+// ---- slot layout of the model tiles ---------------------------------------------------------------
+// A lane owns a quad of rows, and the K index of xty() runs over (quad, register): contraction step
+// s takes register s of every quad.  State and input indices n < 12 are therefore placed at
+//   slot(n) = 4*(n/3) + n%3        (registers 0..2 of quad n/3)
+// and register 3 of every quad is padding -- except slot 3, the homogeneous coordinate.  A product
+// that contracts over states or inputs then needs steps 0..2 only: 3 MFMAs instead of 4 (the
+// homogeneous row of A~ = e_HS is added in the VALU, nmpc_sweep.hpp).
+constexpr int HS = 3;
+__host__ __device__ constexpr int slot_of(int n) { return 4 * (n / 3) + n % 3; }
+__host__ __device__ constexpr int index_of(int slot) { return (slot & 3) == 3 ? -1 : 3 * (slot >> 2) + (slot & 3); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -147,15 +158,17 @@ constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
 // rs_free[j] = 1/sqrt(pivot) of input j when it is uncoupled: its pivot is then the constant
 // R_jj + reg (nothing of B'PB or of the barrier reaches it), so a static mask needs neither the
 // broadcast nor the v_rsq for it.
-template <int NU, unsigned MASK>
+// SLOT3: column j of the system sits in lane slot_of(j) (slot layout) instead of lane j.
+template <int NU, unsigned MASK, bool SLOT3>
 __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, const float (&rs_free)[NU]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
+        const int lane_j = SLOT3 ? slot_of(j) : j;   // a constant after unrolling
         if (MASK != DYNAMIC_MASK && !((MASK >> j) & 1u)) {
             col[j] = col[j] * rs_free[j];
         } else {
-            const float d = bcast(col[j], j);
+            const float d = bcast(col[j], lane_j);
             ok = ok && (d > 0.0f);
             // row j leaves as col[j]/sqrt(d); the multiplier row col[j]/d is that times 1/sqrt(d)
             // again (one v_rsq per pivot and no reciprocal on the dependent chain)
@@ -166,7 +179,7 @@ __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled
 #pragma unroll
                 for (int i = j + 1; i < NU; ++i) {
                     if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
-                        const float l = bcast(col[i], j);
+                        const float l = bcast(col[i], lane_j);
                         col[i] = fmaf(-l, w, col[i]);
                     }
                 }
