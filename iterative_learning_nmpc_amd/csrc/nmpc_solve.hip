@@ -382,27 +382,54 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     float* Kt = ws + wl.Kt;   // transposed images of K~ (N + 1 scratch slot)
     float* Ct = ws + wl.Ct;   // transposed images of Acl~ = A~ + B~K~ (N + 1)
 
-    for (int i = lane; i < L.conv; i += 64) smem[i] = 0.0f;   // padding entries stay finite
+    for (int i = 4 * lane; i < L.conv; i += 256)                // padding entries stay finite
+        *reinterpret_cast<f32x4*>(smem + i) = zero4();
     wave_sync();
-    for (int e = lane; e < (N + 1) * NX; e += 64) {
-        const int k = e / NX;
-        AT(Xs, k, e - k * NX) = Xg[e];
-        qv[k * TS + slot_of(e - k * NX)] = ws[wl.q + e];     // sweep operands are indexed by slot
-    }
-    for (int e = lane; e < N * NU; e += 64) {
-        const int k = e / NU;
-        AT(Us, k, e - k * NU) = Ug[e];
-        rv[k * TS + slot_of(e - k * NU)] = ws[wl.r + e];
+    // Stream the problem into the LDS through registers, PRE floats per lane and array at a time,
+    // with the loads of ALL arrays in flight before the first is used (an element-wise copy loop
+    // pays one memory round trip per 64 floats -- some thirty in a row for a horizon of 50).
+    constexpr int PRE = 13;
+    auto fetch = [&](const float* src, int total, int base, float (&v)[PRE]) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = base + 64 * u + lane;
+            v[u] = src[e < total ? e : 0];
+        }
+    };
+    auto drain = [&](int total, int base, const float (&v)[PRE], auto&& sink) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = base + 64 * u + lane;
+            if (e < total) sink(e, v[u]);
+        }
+    };
+    auto put_x = [&](int e, float v) { const int k = e / NX; AT(Xs, k, e - k * NX) = v; };
+    auto put_q = [&](int e, float v) { const int k = e / NX; qv[k * TS + slot_of(e - k * NX)] = v; };   // by slot
+    auto put_u = [&](int e, float v) { const int k = e / NU; AT(Us, k, e - k * NU) = v; };
+    auto put_r = [&](int e, float v) { const int k = e / NU; rv[k * TS + slot_of(e - k * NU)] = v; };
+    auto put_c = [&](int e, float cj) {                        // c = G u - h at the linearisation point
+        const int k = e / NG, j = e - k * NG;
+        const float s = fmaxf(-cj, a.s_min);
+        AT(sv, k, j) = s;
+        AT(lv, k, j) = a.mu0 * fast_rcp(s);
+    };
+    const int n_x = (N + 1) * NX, n_u = N * NU, n_c = N * NG;
+    const int n_max = n_x > n_c ? n_x : n_c;
+    for (int base = 0; base < n_max; base += 64 * PRE) {
+        float vx[PRE], vq[PRE], vu[PRE], vr[PRE], vc[PRE];
+        fetch(Xg, n_x, base, vx);
+        fetch(ws + wl.q, n_x, base, vq);
+        fetch(Ug, n_u, base, vu);
+        fetch(ws + wl.r, n_u, base, vr);
+        fetch(ws + wl.c, n_c, base, vc);
+        drain(n_x, base, vx, put_x);
+        drain(n_x, base, vq, put_q);
+        drain(n_u, base, vu, put_u);
+        drain(n_u, base, vr, put_r);
+        drain(n_c, base, vc, put_c);
     }
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
-    for (int e = lane; e < N * NG; e += 64) {
-        const int k = e / NG, j = e - k * NG;
-        const float cj = ws[wl.c + e];           // c = G u - h at the linearisation point
-        const float s = fmaxf(-cj, a.s_min);
-        AT(sv, k, j) = s;
-        AT(lv, k, j) = a.mu0 / s;
-    }
     for (int k = lane; k <= N; k += 64) {
         cost_l += ws[wl.cost + k];
         if (k < N) {
