@@ -151,9 +151,61 @@ __device__ __forceinline__ f32x4 lds_load_acc_t(const float* t, int lane) {
 // diagonal (a masked-out input: zero column of B, no active constraint row) has all multipliers
 // equal to zero, so its update loop is skipped -- bit-identical result.
 //   MASK != DYNAMIC_MASK: the mask is a compile-time constant; inactive pivots AND inactive rows
-//   vanish from the unrolled code and the elimination is straight-line code.
+//   vanish from the unrolled code and the elimination is straight-line code (ldl_pairs).
 //   MASK == DYNAMIC_MASK: run-time mask, one wave-uniform branch per pivot.
 constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
+
+// lowest set bit of mask at or above `from` (32 if none)
+__host__ __device__ constexpr int next_bit(unsigned mask, int from) {
+    for (int i = from; i < 32; ++i)
+        if ((mask >> i) & 1u) return i;
+    return 32;
+}
+
+// Static mask: the coupled pivots are eliminated TWO AT A TIME (2x2 block pivots).  The serial part
+// of an LDL' is the chain  pivot -> 1/sqrt -> multipliers -> update -> next pivot ; a block pivot
+// halves the number of links, and all its cross-lane reads (the 2x2 block and the two multiplier
+// columns) are independent of the chain, so they issue ahead of it.  With rows a < b of the pair,
+//   ra = 1/sqrt(d_a)   t = H_ba ra   rb = 1/sqrt(d_b - t^2)
+//   y_a = row_a ra     y_b = (row_b - t y_a) rb                         (the rows as they leave)
+//   row_i -= m_ia y_a + m_ib y_b ,  m_ia = H_ia ra ,  m_ib = (H_ib - m_ia t) rb
+// which is the scalar recursion carried out for a and b at once.  A, the first pivot of the pair,
+// walks over the set bits of MASK.
+template <int NU, unsigned MASK, bool SLOT3, int A>
+__device__ __forceinline__ void ldl_pairs(float (&col)[NU], bool& ok) {
+    constexpr unsigned M = MASK & ((NU < 32) ? ((1u << NU) - 1u) : 0xFFFFFFFFu);
+    if constexpr (A < NU) {
+        constexpr int Bi = next_bit(M, A + 1);
+        constexpr int la = SLOT3 ? slot_of(A) : A;
+        if constexpr (Bi < NU) {
+            constexpr int lb = SLOT3 ? slot_of(Bi) : Bi;
+            const float da = bcast(col[A], la), e = bcast(col[Bi], la), db = bcast(col[Bi], lb);
+            const float ra = __builtin_amdgcn_rsqf(da);
+            const float t = e * ra;
+            const float db2 = fmaf(-t, t, db);
+            const float rb = __builtin_amdgcn_rsqf(db2);
+            ok = ok && (da > 0.0f) && (db2 > 0.0f);
+            const float ya = col[A] * ra;
+            const float yb = fmaf(-t, ya, col[Bi]) * rb;
+#pragma unroll
+            for (int i = Bi + 1; i < NU; ++i) {
+                if ((M >> i) & 1u) {
+                    const float lia = bcast(col[i], la), lib = bcast(col[i], lb);
+                    const float mia = lia * ra;
+                    const float mib = fmaf(-mia, t, lib) * rb;
+                    col[i] = fmaf(-mib, yb, fmaf(-mia, ya, col[i]));
+                }
+            }
+            col[A] = ya;
+            col[Bi] = yb;
+            ldl_pairs<NU, MASK, SLOT3, next_bit(M, Bi + 1)>(col, ok);
+        } else {   // odd one out: the last coupled pivot, nothing left to update
+            const float d = bcast(col[A], la);
+            ok = ok && (d > 0.0f);
+            col[A] = col[A] * __builtin_amdgcn_rsqf(d);
+        }
+    }
+}
 
 // rs_free[j] = 1/sqrt(pivot) of input j when it is uncoupled: its pivot is then the constant
 // R_jj + reg (nothing of B'PB or of the barrier reaches it), so a static mask needs neither the
@@ -162,26 +214,27 @@ constexpr unsigned DYNAMIC_MASK = 0xFFFFFFFFu;
 template <int NU, unsigned MASK, bool SLOT3>
 __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled, const float (&rs_free)[NU]) {
     bool ok = true;
+    if constexpr (MASK != DYNAMIC_MASK) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-        const int lane_j = SLOT3 ? slot_of(j) : j;   // a constant after unrolling
-        if (MASK != DYNAMIC_MASK && !((MASK >> j) & 1u)) {
-            col[j] = col[j] * rs_free[j];
-        } else {
+        for (int j = 0; j < NU; ++j)
+            if (!((MASK >> j) & 1u)) col[j] = col[j] * rs_free[j];
+        ldl_pairs<NU, MASK, SLOT3, next_bit(MASK, 0)>(col, ok);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int lane_j = SLOT3 ? slot_of(j) : j;   // a constant after unrolling
             const float d = bcast(col[j], lane_j);
             ok = ok && (d > 0.0f);
             // row j leaves as col[j]/sqrt(d); the multiplier row col[j]/d is that times 1/sqrt(d)
             // again (one v_rsq per pivot and no reciprocal on the dependent chain)
             const float rs = __builtin_amdgcn_rsqf(d);
             col[j] = col[j] * rs;
-            if (MASK != DYNAMIC_MASK || ((coupled >> j) & 1u)) {
+            if ((coupled >> j) & 1u) {
                 const float w = col[j] * rs;
 #pragma unroll
                 for (int i = j + 1; i < NU; ++i) {
-                    if (MASK == DYNAMIC_MASK || ((MASK >> i) & 1u)) {
-                        const float l = bcast(col[i], lane_j);
-                        col[i] = fmaf(-l, w, col[i]);
-                    }
+                    const float l = bcast(col[i], lane_j);
+                    col[i] = fmaf(-l, w, col[i]);
                 }
             }
         }
