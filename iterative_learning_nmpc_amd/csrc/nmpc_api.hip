@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -24,6 +25,8 @@ struct Handle {
     size_t ws_stride = 0;    // floats per problem
     float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
     float* roll = nullptr;   // rollout problem tensors: x0 alias, yref, yref_e, params (B_max sized)
+    int n_cu = 256;          // compute units of the device
+    int force_variant = 0;   // NMPC_QP_VARIANT: 0 choose by batch size, 1 resident, 2 lean (tests, tuning)
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
@@ -70,24 +73,34 @@ size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
 
 // One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
-template <class M>
-int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
-    const nmpc::Lds<M> L(a.N);
+// Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays while every problem
+// of the batch gets a SIMD of its own, the lean layout (two waves per SIMD) beyond that.
+template <class M, bool LEAN>
+int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
+    const nmpc::Lds<M, LEAN> L(a.N);
     const size_t bytes = (size_t)L.total * sizeof(float);
-    if (bytes > 160 * 1024 || a.N > 64 * nmpc::N_LANE_STAGES)
-        return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
+    if (bytes > 160 * 1024) return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
     if (bytes > 64 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    const long long nthreads = (long long)a.B * (a.N + 1);
-    const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
     for (int it = 0; it < a.max_sqp; ++it) {
         a.it = it;
         hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(nmpc::nmpc_qp_kernel<M>, dim3(a.B), dim3(64), bytes, st, a);
+        hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN>), dim3(a.B), dim3(64), bytes, st, a);
     }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
+}
+
+template <class M>
+int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
+    if (a.N > 64 * nmpc::N_LANE_STAGES) return fail(h, NMPC_E_ARG, "horizon too long for the lane = stage phases");
+    const long long nthreads = (long long)a.B * (a.N + 1);
+    const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
+    const size_t resident_bytes = (size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float);
+    const long long resident_waves = resident_bytes <= 160 * 1024 ? (long long)h->n_cu * (long long)((160 * 1024) / resident_bytes) : 0;
+    const bool lean = h->force_variant ? (h->force_variant > 1) : (a.B > resident_waves);
+    return lean ? launch_qp<M, true>(h, a, st, lin_blocks) : launch_qp<M, false>(h, a, st, lin_blocks);
 }
 
 template <class M>
@@ -152,6 +165,11 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     h->device = device_id;
     h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
     hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
+    if (const char* v = std::getenv("NMPC_QP_VARIANT")) {
+        if (!std::strcmp(v, "resident")) h->force_variant = 1;
+        else if (!std::strcmp(v, "lean")) h->force_variant = 2;
+    }
     if (e == hipSuccess) {
         h->ws_stride = (dims->model_id == NMPC_MODEL_DOUBLE_INTEGRATOR)
                            ? ws_floats_per_problem<nmpc::DoubleIntegrator>(dims->N)

@@ -153,13 +153,36 @@ struct RowStoreLane {
     }
 };
 
+// Arrays of the lane = stage phases (trajectories, steps, slacks, multipliers): FEATURE-major,
+// [feature][stage] with an odd stage stride NS, so consecutive lanes touch consecutive banks (LDS)
+// or consecutive addresses (workspace).  Offsets in floats from the start of the group.
+template <class M>
+struct StageArrays {
+    int NS;   // stage stride (odd, >= N+1)
+    int Xs, Us, dX, dU, dXp, dUp, sv, lv, total;
+    __host__ __device__ explicit StageArrays(int N) {
+        NS = (N + 1) | 1;
+        int o = 0;
+        Xs = o;  o += round4(M::NX * NS);
+        Us = o;  o += round4(M::NU * NS);
+        dX = o;  o += round4(M::NX * NS);
+        dU = o;  o += round4(M::NU * NS);
+        dXp = o; o += round4(M::NX * NS);
+        dUp = o; o += round4(M::NU * NS);
+        sv = o;  o += round4(M::NG * NS);
+        lv = o;  o += round4(M::NG * NS);
+        o += 4;                                   // sink for the idle lanes of the forward sweep
+        total = o;
+    }
+};
+
 // Workspace of one problem (float offsets): stage images A~[N], B~[N], K~[N+1], Acl~[N+1]
 // (the extra slot is scratch for the software pipeline), then what the linearisation hands to the
 // QP kernel: gradients q[N+1][nx], r[N][nu], constraint values c[N][ng], masks, stage costs, and
 // the problem's "finished" flag.
 template <class M>
 struct WsLayout {
-    size_t At, Bt, Kt, Ct, q, r, c, act, umk, cost, flag, stride;
+    size_t At, Bt, Kt, Ct, q, r, c, act, umk, cost, flag, lean, stride;
     __host__ __device__ explicit WsLayout(int N) {
         size_t o = 0;
         At = o; o += (size_t)N * TileGeom<M>::A_FLOATS;
@@ -173,6 +196,7 @@ struct WsLayout {
         umk = o; o += round4(N);
         cost = o; o += round4(N + 1);
         flag = o; o += 4;
+        lean = o; o += StageArrays<M>(N).total;     // lane = stage arrays of the lean-LDS kernel variant
         stride = (o + 63) & ~(size_t)63;
     }
 };
@@ -193,30 +217,24 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 #define SST_TILES(i)
 #endif
 
-// LDS layout of one problem.  Arrays of the lane = stage phases (trajectories, steps, slacks,
-// multipliers) are FEATURE-major, [feature][stage] with an odd stage stride NS, so consecutive lanes
-// touch consecutive banks.
-template <class M>
+// LDS layout of one problem.  Two variants of the QP kernel:
+//   resident (LEAN = false): stage arrays + sweep operands + conversion tiles, 39.6 KB at N = 50 ->
+//       4 waves per CU, one per SIMD: the fastest single wave, used while the batch fits that way;
+//   lean (LEAN = true): the stage arrays live in the workspace, 18.4 KB -> 8 waves per CU.  Two
+//       waves per SIMD fill each other's stalls and double the VALU issue rate.
+template <class M, bool LEAN>
 struct Lds {
-    int NS;   // stage stride (odd, >= N+1)
-    int Xs, Us, dX, dU, dXp, dUp, qv, rv, sv, lv, gsq, gvt, act, umk, conv, total;   // float offsets
+    int arr, qv, rv, gsq, gvt, act, umk, conv, total;   // float offsets
     __host__ __device__ explicit Lds(int N) {
-        NS = (N + 1) | 1;
+        const int NS = (N + 1) | 1;
         int o = 0;
-        Xs = o;  o += round4(M::NX * NS);
-        Us = o;  o += round4(M::NU * NS);
-        dX = o;  o += round4(M::NX * NS);
-        dU = o;  o += round4(M::NU * NS);
-        dXp = o; o += round4(M::NX * NS);
-        dUp = o; o += round4(M::NU * NS);
+        arr = o; o += LEAN ? 0 : StageArrays<M>(N).total;
         // sweep operands are STAGE-major, 16 floats per stage: the four tile registers of a lane
         // are one 16 B read (only the stage sweeps touch them after they are written)
         qv = o;  o += (N + 1) * TS;
         rv = o;  o += N * TS;
         gsq = o; o += N * TS;
         gvt = o; o += N * TS;
-        sv = o;  o += round4(M::NG * NS);
-        lv = o;  o += round4(M::NG * NS);
         act = o; o += round4(NS);
         umk = o; o += round4(NS);
         conv = o; o += CONV_TILES * CTILE;
@@ -342,9 +360,30 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     for (int j = 0; j < NG; ++j) ws[wl.c + (size_t)k * NG + j] = g[j] - M::h(a.mp, j);
 }
 
+// Element-wise pass over n floats, lane-strided, with PRE loads per lane in flight before the first
+// result is stored: ld(i) computes the value of element i from its loads, st(i, v) consumes it.
+// (In the lean variant these are memory round trips; a plain loop would serialise them, since the
+// compiler must assume that a store may alias the next iteration's loads.)
+template <int PRE, class Load, class Store>
+__device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) {
+    for (int base = 0; base < n; base += 64 * PRE) {
+        float v[PRE];
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int i = base + 64 * u + lane;
+            v[u] = ld(i < n ? i : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int i = base + 64 * u + lane;
+            if (i < n) st(i, v[u]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // QP + step of one SQP iteration: one problem per wavefront.
-template <class M>
+template <class M, bool LEAN>
 __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
@@ -358,14 +397,25 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     float* ws = a.ws + (size_t)b * wl.stride;
     int* flag = reinterpret_cast<int*>(ws + wl.flag);
     if (a.it > 0 && flag[0]) return;             // finished in an earlier iteration
-    const Lds<M> L(N);
-    const int NS = L.NS;
-    float* Xs = smem + L.Xs;   float* Us = smem + L.Us;
-    float* dX = smem + L.dX;   float* dU = smem + L.dU;
-    float* dXp = smem + L.dXp; float* dUp = smem + L.dUp;
+    const Lds<M, LEAN> L(N);
+    const StageArrays<M> SA_(N);
+    const int NS = SA_.NS;
+    // the stage arrays: LDS in the resident variant, workspace in the lean one (same code either way;
+    // the variant is a template parameter so that every pointer has ONE address space)
+    float* arr = LEAN ? ws + wl.lean : smem + L.arr;
+    float* Xs = arr + SA_.Xs;   float* Us = arr + SA_.Us;
+    float* dX = arr + SA_.dX;   float* dU = arr + SA_.dU;
+    float* dXp = arr + SA_.dXp; float* dUp = arr + SA_.dUp;
+    float* sv = arr + SA_.sv;   float* lv = arr + SA_.lv;
+    float* idle_sink = arr + SA_.total - 4;
     float* qv = smem + L.qv;   float* rv = smem + L.rv;
-    float* sv = smem + L.sv;   float* lv = smem + L.lv;
     float* gsq = smem + L.gsq; float* gvt = smem + L.gvt;
+    // ordering point between phases that exchange data between lanes: LDS traffic of a single wave
+    // is ordered by issue; the workspace needs the stores drained first
+    auto phase_sync = [&]() {
+        if constexpr (LEAN) __threadfence_block();
+        wave_sync();
+    };
     unsigned* actm = reinterpret_cast<unsigned*>(smem + L.act);
     unsigned* umask = reinterpret_cast<unsigned*>(smem + L.umk);
     float* conv = smem + L.conv;
@@ -384,7 +434,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
 
     for (int i = 4 * lane; i < L.conv; i += 256)                // padding entries stay finite
         *reinterpret_cast<f32x4*>(smem + i) = zero4();
-    wave_sync();
+    if constexpr (LEAN)
+        for (int i = 4 * lane; i < SA_.total; i += 256) *reinterpret_cast<f32x4*>(arr + i) = zero4();
+    phase_sync();
     // Stream the problem into the LDS through registers, PRE floats per lane and array at a time,
     // with the loads of ALL arrays in flight before the first is used (an element-wise copy loop
     // pays one memory round trip per 64 floats -- some thirty in a row for a horizon of 50).
@@ -467,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
         Gc[r] = (row < NG && c_is_u) ? M::G(a.mp, row < NG ? row : 0, c_is_u ? ic : 0) : 0.0f;   // rows: constraints
     }
     const bool is_hx_col = (c == HS);
-    wave_sync();
+    phase_sync();
 
     int status = NMPC_STATUS_MAXITER;
     bool finished = false;
@@ -483,6 +535,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
         bool qp_ok = true;
         float mu_sum = wave_sum(mu_l);          // sum of s.lam over the active rows
         const bool one_stage_per_lane = N <= 64;
+        // step <- step + ap (new step - step), both trajectories
+        auto blend = [&](float ap) {
+            batched<10>(NX * NS, lane, [&](int i) { const float d = dX[i]; return d + ap * (dXp[i] - d); },
+                        [&](int i, float v) { dX[i] = v; });
+            batched<10>(NU * NS, lane, [&](int i) { const float d = dU[i]; return d + ap * (dUp[i] - d); },
+                        [&](int i, float v) { dU[i] = v; });
+        };
         for (int ii = 0; ii < n_sweeps; ++ii) {
             float tau = 0.0f;
             if (use_ipm) {
@@ -509,7 +568,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                         gvt[k * TS + j] = on ? (tau * is + l + D * cj) * rs : 0.0f;
                     }
                 }
-                wave_sync();
+                phase_sync();
             }
             STAMP(1);
             // -------------------------------------------------------- phase R: backward sweep
@@ -651,7 +710,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                 }
             };
             if (use_ipm) sweep(std::true_type{}); else sweep(std::false_type{});
-            __threadfence_block();
+            __threadfence_block();          // K~/Acl~ images: stored above, read by other lanes below
             wave_sync();
             STAMP(2);
             // -------------------------------------------------------- phase F: forward sweep
@@ -671,7 +730,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             // row of this lane in the image of stage 0, as a byte offset from the workspace base
             unsigned rowoff = 4u * (unsigned)((is_x ? wl.Ct : wl.Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS);
             const unsigned rowstep = 4u * (is_x ? G::C_FLOATS : G::K_FLOATS);
-            float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : (conv + 2 * CTILE);
+            float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : idle_sink;
             const int dstep = (is_x || is_u) ? 1 : 0;
             // the used floats of a row: quad 0 (three states and the homogeneous slot) as a 16 B load,
             // the other quads as 12 B loads (a load with dead elements lets the allocator reuse them at
@@ -711,7 +770,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
 #pragma unroll
             for (int j = 0; j < FWD_PF - 1; ++j)          // the last N % FWD_PF stages
                 if (k0 + j < N) fwd_stage(k0 + j, ring[j]);
-            wave_sync();
+            phase_sync();
             STAMP(3);
             // -------------------------------------------------------- phase I: IPM update
             if (use_ipm && one_stage_per_lane) {
@@ -752,8 +811,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     m_l += on ? s[j] * l[j] : 0.0f;
                 }
                 mu_sum = wave_sum(m_l);
-                for (int i = lane; i < NX * NS; i += 64) dX[i] += ap * (dXp[i] - dX[i]);
-                for (int i = lane; i < NU * NS; i += 64) dU[i] += ap * (dUp[i] - dU[i]);
+                blend(ap);
                 if (ii + 1 < n_sweeps && live) {
                     const float tau_n = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
                     float sq[NG], vt[NG];
@@ -769,7 +827,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
 #pragma unroll
                     for (int j = 0; j < NG; ++j) { gsq[k * TS + j] = sq[j]; gvt[k * TS + j] = vt[j]; }
                 }
-                wave_sync();
+                phase_sync();
             } else if (use_ipm) {
                 float ap_l = 1.0f, ad_l = 1.0f;
                 // long horizons (several stages per lane): the same update in two passes.
@@ -823,25 +881,20 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     }
                 }
                 mu_sum = wave_sum(m_l);
-                for (int i = lane; i < NX * NS; i += 64) dX[i] += ap * (dXp[i] - dX[i]);
-                for (int i = lane; i < NU * NS; i += 64) dU[i] += ap * (dUp[i] - dU[i]);
-                wave_sync();
+                blend(ap);
+                phase_sync();
             }
         }
         STAMP(4);
         // ------------------------------------------------------------ phase S: step
         float sn_l = 0.0f;
         bool bad_l = false;
-        for (int i = lane; i < NX * NS; i += 64) {
-            const float v = dX[i];
+        auto step_norm = [&](int, float v) {
             bad_l = bad_l || !(fabsf(v) <= 1e30f);
             sn_l = fmaxf(sn_l, fabsf(v));
-        }
-        for (int i = lane; i < NU * NS; i += 64) {
-            const float v = dU[i];
-            bad_l = bad_l || !(fabsf(v) <= 1e30f);
-            sn_l = fmaxf(sn_l, fabsf(v));
-        }
+        };
+        batched<10>(NX * NS, lane, [&](int i) { return dX[i]; }, step_norm);
+        batched<10>(NU * NS, lane, [&](int i) { return dU[i]; }, step_norm);
         stepn = wave_max(sn_l);
         const bool bad = __any(bad_l);
         if (bad) { status = NMPC_STATUS_NAN; finished = true; }
@@ -898,16 +951,18 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             }
         }
         if (!bad) {
-            for (int i = lane; i < NX * NS; i += 64) Xs[i] += alpha * dX[i];
-            for (int i = lane; i < NU * NS; i += 64) Us[i] += alpha * dU[i];
-            wave_sync();
+            batched<10>(NX * NS, lane, [&](int i) { return Xs[i] + alpha * dX[i]; }, [&](int i, float v) { Xs[i] = v; });
+            batched<10>(NU * NS, lane, [&](int i) { return Us[i] + alpha * dU[i]; }, [&](int i, float v) { Us[i] = v; });
+            phase_sync();
             if (!qp_ok) { status = NMPC_STATUS_QP; finished = true; }
             else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }
         }
     }
     if (status != NMPC_STATUS_NAN) {   // a NaN step leaves the iterate of the previous iteration
-        for (int e = lane; e < (N + 1) * NX; e += 64) { const int k = e / NX; Xg[e] = AT(Xs, k, e - k * NX); }
-        for (int e = lane; e < N * NU; e += 64) { const int k = e / NU; Ug[e] = AT(Us, k, e - k * NU); }
+        batched<10>((N + 1) * NX, lane, [&](int e) { const int k = e / NX; return AT(Xs, k, e - k * NX); },
+                    [&](int e, float v) { Xg[e] = v; });
+        batched<10>(N * NU, lane, [&](int e) { const int k = e / NU; return AT(Us, k, e - k * NU); },
+                    [&](int e, float v) { Ug[e] = v; });
     }
     STAMP(5);
 #ifdef NMPC_STAMPS
