@@ -406,3 +406,41 @@ def test_device_rollout_matches_host_driven_rollout(dev):
     assert np.allclose(refh, refd, rtol=0, atol=1e-12)
     assert rel(Sd, Sh) < 2e-5 and rel(Sd2, Sh2) < 2e-5 and rel(Xd, Xh) < 2e-5, (rel(Sd, Sh), rel(Sd2, Sh2), rel(Xd, Xh))
     assert np.abs(Sd[1:, -1] - Sd[0, -1]).max() > 1e-3          # the pushes did something
+
+
+# ----------------------------------------------------------------------------- kernel variants
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,N,opts", [(1, 50, dict(n_ipm=6, max_sqp_iter=2)), (1, 70, dict(n_ipm=6)),
+                                          (0, 20, dict(n_ipm=6)), (1, 50, dict(n_ipm=6, line_search=1))])
+def test_lean_variant_is_bit_identical_to_resident(dev, monkeypatch, model, N, opts):
+    """The lean-LDS variant of the QP kernel (stage arrays in the workspace) runs the same
+    arithmetic in the same order as the resident one: trajectories, status and stats agree bit for bit."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B = 6
+    w = wl.centroidal_trot(B=B, N=N, seed=13) if model == 1 else wl.double_integrator(B=B, N=N, seed=13, umax=1.2)
+    out = {}
+    for variant in ("resident", "lean"):
+        monkeypatch.setenv("NMPC_QP_VARIANT", variant)       # read by nmpc_create
+        out[variant] = _gpu_solve(_solver(w, B, dev, **opts), w)
+    for a, b in zip(out["resident"], out["lean"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_batch_beyond_one_wave_per_simd_switches_variant(dev, oracle32, monkeypatch):
+    """B > 4 waves/CU x CUs takes the lean variant by itself; its result equals the forced-resident one
+    and both match the oracle on a sample of the batch."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    monkeypatch.delenv("NMPC_QP_VARIANT", raising=False)
+    B = 1100
+    w = wl.centroidal_trot(B=B, N=50, seed=17)
+    X, U, st, _ = _gpu_solve(_solver(w, B, dev), w)
+    monkeypatch.setenv("NMPC_QP_VARIANT", "resident")
+    Xr, Ur, str_, _ = _gpu_solve(_solver(w, B, dev), w)
+    assert np.array_equal(X, Xr) and np.array_equal(U, Ur) and np.array_equal(st, str_)
+    sel = slice(B - 24, B)                                    # the tail of the batch: the second round
+    ws = wl.centroidal_trot(B=B, N=50, seed=17)
+    Xo, Uo, sto, _ = oracle32.solve_batch(ws.model_id, ws.N, ws.mp, oracle32.opt(yref_per_stage=1, reg=ws.meta["reg"], reg_e=ws.meta["reg_e"]),
+                                          ws.W, ws.W_e, ws.x0[sel], ws.yref[sel], ws.yref_e[sel], ws.params[sel], ws.X[sel], ws.U[sel])
+    assert rel(X[sel], Xo) < 2e-5 and rel(U[sel], Uo) < 2e-5
+    assert np.array_equal(st[sel], sto)
