@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--ipm", type=int, default=6)
     ap.add_argument("--sqp", type=int, default=1)
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
+                    help="0: fp32 (headline); 1: bf16 barrier product, BASELINE configs[4] (a different config, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rollouts", type=int, default=0,
                     help="extra mode (not the headline metric): B rollouts per GPU of 2 s (50 replans) fully "
@@ -169,7 +171,7 @@ def main():
 
     B, N = a.batch, 50
     w = wl.centroidal_trot(B=B, N=N, seed=1000 * rank)
-    s = BatchedNmpcSolver(w.model_id, N, B, dev)
+    s = BatchedNmpcSolver(w.model_id, N, B, dev, precision=a.precision)
     s.set_model_params(w.mp)
     s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
     s.set_max_iter(a.sqp)
@@ -223,8 +225,9 @@ def main():
             "value": world * B * a.steps / elapsed, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 fp32, "
+            "vs_baseline": None, "dtype": "f32" if a.precision == 0 else "f32 (bf16 barrier product)", "data": "synthetic",
+            "config": {"workload": f"configs[{1 if a.precision == 0 else 4}]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 "
+                                   f"{'fp32' if a.precision == 0 else 'mixed precision (bf16 MFMA barrier product, fp32 Riccati)'}, "
                                    f"{a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step",
                        "global_batch": world * B, "horizon": N, "parallelism": f"dp{world} (independent problems, no collective)"},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

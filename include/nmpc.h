@@ -64,7 +64,9 @@ typedef struct {
     int model_id;  /* NMPC_MODEL_*                                             */
     int N;         /* horizon (number of shooting intervals)                  */
     int B_max;     /* largest batch a *_batch call will be given              */
-    int precision; /* 0 = fp32 (only value implemented)                       */
+    int precision; /* 0 = fp32; 1 = mixed: the interior-point barrier product  */
+                   /* G'DG | G'v (the J'WJ contraction of the QP) in bf16 on   */
+                   /* the matrix pipe, everything else fp32 (BASELINE cfg 5)   */
 } nmpc_dims;
 
 /* Dimensions of a model.  Any out pointer may be NULL. */

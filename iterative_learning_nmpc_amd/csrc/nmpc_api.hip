@@ -75,18 +75,18 @@ size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
 // Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays while every problem
 // of the batch gets a SIMD of its own, the lean layout (two waves per SIMD) beyond that.
-template <class M, bool LEAN>
+template <class M, bool LEAN, bool BF16B>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
     const nmpc::Lds<M, LEAN> L(a.N);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024) return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
     if (bytes > 64 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN, BF16B>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     for (int it = 0; it < a.max_sqp; ++it) {
         a.it = it;
         hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
-        hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN>), dim3(a.B), dim3(64), bytes, st, a);
+        hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN, BF16B>), dim3(a.B), dim3(64), bytes, st, a);
     }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
@@ -100,7 +100,9 @@ int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     const size_t resident_bytes = (size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float);
     const long long resident_waves = resident_bytes <= 160 * 1024 ? (long long)h->n_cu * (long long)((160 * 1024) / resident_bytes) : 0;
     const bool lean = h->force_variant ? (h->force_variant > 1) : (a.B > resident_waves);
-    return lean ? launch_qp<M, true>(h, a, st, lin_blocks) : launch_qp<M, false>(h, a, st, lin_blocks);
+    if (h->dims.precision == 1)
+        return lean ? launch_qp<M, true, true>(h, a, st, lin_blocks) : launch_qp<M, false, true>(h, a, st, lin_blocks);
+    return lean ? launch_qp<M, true, false>(h, a, st, lin_blocks) : launch_qp<M, false, false>(h, a, st, lin_blocks);
 }
 
 template <class M>
@@ -159,7 +161,8 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     int nx, nu, np, ng;
     if (nmpc_model_dims(dims->model_id, &nx, &nu, &np, &ng)) return fail(nullptr, NMPC_E_ARG, "unknown model_id");
     if (dims->N < 1 || dims->B_max < 1) return fail(nullptr, NMPC_E_ARG, "N and B_max must be positive");
-    if (dims->precision != 0) return fail(nullptr, NMPC_E_ARG, "only precision 0 (fp32) is implemented");
+    if (dims->precision != 0 && dims->precision != 1)
+        return fail(nullptr, NMPC_E_ARG, "precision must be 0 (fp32) or 1 (bf16 barrier product)");
     Handle* h = new Handle();
     h->dims = *dims;
     h->device = device_id;

@@ -383,7 +383,9 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 
 // ------------------------------------------------------------------------------------------------
 // QP + step of one SQP iteration: one problem per wavefront.
-template <class M, bool LEAN>
+// LEAN: LDS layout variant (Lds).  BF16B: the barrier product Gs'[Gs | vt] on the bf16 matrix pipe
+// (nmpc_dims.precision = 1, BASELINE configs[4]); everything else stays fp32.
+template <class M, bool LEAN, bool BF16B>
 __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
@@ -630,7 +632,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                         }
                     }
                     __device__ __forceinline__ void mfma(int i) {
-                        if constexpr (IPM) Tb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Tb, 0, 0, 0);
+                        if constexpr (IPM && !BF16B) Tb = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[i], Vt[i], Tb, 0, 0, 0);
+                        if constexpr (IPM && BF16B) { if (i == 0) Tb = xty_bf16(Gs, Vt); }
                     }
                     __device__ __forceinline__ void finish() {
                         if constexpr (IPM) {

@@ -41,6 +41,24 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16 operands (mixed-precision barrier product, nmpc_dims.precision = 1) --------------------
+// The accumulator layout of a 16-row tile is also the operand layout of v_mfma_f32_16x16x16_bf16:
+// lane (q, c) holds k = 4q..4q+3 of row/column c.  X'Y over all 16 rows is then ONE instruction on
+// the bf16 matrix pipe instead of four fp32 steps.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {       // two v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
+    const bf16x2 hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+    const u32x2 p = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    return __builtin_bit_cast(s16x4, p);
+}
+__device__ __forceinline__ f32x4 xty_bf16(f32x4 X, f32x4 Y) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(X), to_bf16x4(Y), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
+
 // C + X'Y  (all three in accumulator layout)
 __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y, f32x4 C) {
     C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], C, 0, 0, 0);

@@ -36,7 +36,7 @@ class BatchedNmpcSolver:
     """B independent NMPC problems of one model, solved together (one problem per wavefront)."""
 
     def __init__(self, model_id: int, n_nodes: int, batch_max: int, device="cuda:0",
-                 compute_timings: bool = False):
+                 compute_timings: bool = False, precision: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedNmpcSolver needs a HIP device; there is no CPU path")
         self.lib = _lib.load()
@@ -48,7 +48,9 @@ class BatchedNmpcSolver:
         self.compute_timings = compute_timings
         self.timings = defaultdict(list)
         self.last_node = 0
-        dims = _lib.NmpcDims(self.model_id, self.n_nodes, self.batch_max, 0)
+        # precision 0: fp32 throughout; 1: bf16 barrier product (mixed precision), see include/nmpc.h
+        self.precision = int(precision)
+        dims = _lib.NmpcDims(self.model_id, self.n_nodes, self.batch_max, self.precision)
         self._h = ctypes.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.nmpc_create(ctypes.byref(dims), dev_index, ctypes.byref(self._h)), None, "nmpc_create")

@@ -444,3 +444,27 @@ def test_batch_beyond_one_wave_per_simd_switches_variant(dev, oracle32, monkeypa
                                           ws.W, ws.W_e, ws.x0[sel], ws.yref[sel], ws.yref_e[sel], ws.params[sel], ws.X[sel], ws.U[sel])
     assert rel(X[sel], Xo) < 2e-5 and rel(U[sel], Uo) < 2e-5
     assert np.array_equal(st[sel], sto)
+
+
+@pytest.mark.gpu
+def test_mixed_precision_barrier_product(dev, oracle64):
+    """BASELINE configs[4]: precision = 1 computes the interior-point barrier product G'DG | G'v with
+    ONE bf16 MFMA (inputs rounded to 8 bits of mantissa) and everything else in fp32.  The measured
+    outcome is negative and the test pins it: the barrier terms dominate Huu near active constraints,
+    their 0.4 % rounding perturbs every Newton direction, and after six interior-point iterations the
+    trajectories differ from the fp64 oracle by 8e-2 (X) / 3e-2 (U) relative -- four orders above the
+    fp32 path, for 2 % more throughput.  Emulating the rounding in fp32 arithmetic gives
+    the same deviation, so it is the precision, not the instruction."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    B = 16
+    w = wl.centroidal_trot(B=B, N=50, seed=2)
+    s = BatchedNmpcSolver(w.model_id, w.N, B, dev, precision=1)
+    s.set_model_params(w.mp)
+    s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+    X, U, st, _ = _gpu_solve(s, w)
+    Xo, Uo, sto, _ = _oracle_solve(oracle64, w)
+    eX, eU = rel(X, Xo), rel(U, Uo)
+    print(f"mixed precision: rel-L2 X {eX:.2e} U {eU:.2e}")
+    assert np.array_equal(st, sto)
+    assert 1e-4 < eX < 0.25 and eU < 0.25, (eX, eU)      # runs, converges to the neighbourhood, is NOT the fp32 path

@@ -37,6 +37,10 @@ d = dbg.cpu().numpy().astype(np.float64)
 names = ["linearise", "ipm upd+coef", "backward", "forward", "last ipm upd", "step+store"]
 tot = d[:, :6].sum(1).mean()
 print(f"B={B} {extra}: mean cycles per wave {tot:.0f}")
+tw = d[:, :6].sum(1)
+print(f"  per-wave total: min {tw.min():.0f}  p50 {np.median(tw):.0f}  p90 {np.percentile(tw, 90):.0f}  max {tw.max():.0f}  (the kernel lasts as long as its slowest wave)")
+bw = d[:, 2]
+print(f"  per-wave backward: min {bw.min():.0f}  p50 {np.median(bw):.0f}  max {bw.max():.0f}")
 for i, n in enumerate(names):
     print(f"  {n:12s} {d[:, i].mean():10.0f} cycles  {100 * d[:, i].mean() / tot:5.1f} %")
 seg = ["products PA..Hxx", "LDS -> columns", "LDL' elimination", "columns -> LDS -> acc", "K, P+, Acl", "stores + loop", "cost tiles (+IPM MFMA)"]
