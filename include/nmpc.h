@@ -109,6 +109,14 @@ int nmpc_solve_batch(void *handle, int B, const float *x0, const float *yref, in
                      const float *yref_e, const float *params, float *X, float *U, int *status,
                      float *stats, void *stream);
 
+/* nmpc_shift_warm_start(shift) followed by nmpc_solve_batch, as ONE operation: the kernels of the
+ * first SQP iteration read the previous solution in X, U through the shift's index map, so the
+ * warm start of the receding-horizon loop (solver.py:304-322 then :396-403) costs no launch and no
+ * pass over memory.  Results are identical to the two calls.  shift = 0 is nmpc_solve_batch. */
+int nmpc_shift_solve_batch(void *handle, int B, int shift, const float *x0, const float *yref,
+                           int yref_per_stage, const float *yref_e, const float *params, float *X,
+                           float *U, int *status, float *stats, void *stream);
+
 /* One Riccati sweep on explicit stage data (the LQ core of the solve), dense row-major dev
  * inputs Q[B][N+1][nx][nx] R[B][N][nu][nu] q[B][N+1][nx] r[B][N][nu] A[B][N][nx][nx]
  * B_[B][N][nx][nu] d[B][N][nx] dx0[B][nx]; outputs dX[B][N+1][nx] dU[B][N][nu] status[B].

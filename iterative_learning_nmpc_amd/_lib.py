@@ -27,6 +27,8 @@ SIGNATURES = {
     "nmpc_shift_warm_start": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_solve_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_shift_solve_batch": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nmpc_riccati_batch": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 12),
     "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p]),

@@ -83,8 +83,10 @@ int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks)
     if (bytes > 64 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN, BF16B>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int shift = a.shift;
     for (int it = 0; it < a.max_sqp; ++it) {
         a.it = it;
+        a.shift = (it == 0) ? shift : 0;     // later iterations read their own iterate
         hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
         hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN, BF16B>), dim3(a.B), dim3(64), bytes, st, a);
     }
@@ -284,14 +286,15 @@ int nmpc_shift_warm_start(void* handle, int B, int shift, float* X, float* U, vo
     return NMPC_OK;
 }
 
-int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, int yref_per_stage,
-                     const float* yref_e, const float* params, float* X, float* U, int* status,
-                     float* stats, void* stream) {
+int nmpc_shift_solve_batch(void* handle, int B, int shift, const float* x0, const float* yref,
+                           int yref_per_stage, const float* yref_e, const float* params, float* X, float* U,
+                           int* status, float* stats, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return NMPC_E_ARG;
     if (B == 0) return NMPC_OK;     // an empty batch is a no-op (its tensors have no storage)
     if (!x0 || !yref || !yref_e || !X || !U || (h->np > 0 && !params)) return fail(h, NMPC_E_ARG, "null argument");
     if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (shift < 0) return fail(h, NMPC_E_ARG, "negative shift");
     if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
@@ -301,11 +304,18 @@ int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, in
     }
     nmpc::SolveArgs a = base_args(h);
     a.B = B;
+    a.shift = shift > h->dims.N ? h->dims.N : shift;
     a.yref_per_stage = yref_per_stage ? 1 : 0;
     a.x0 = x0; a.yref = yref; a.yref_e = yref_e; a.params = params ? params : x0;
     a.X = X; a.U = U; a.status = status; a.stats = stats;
     if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return launch_solve<nmpc::DoubleIntegrator>(h, a, st);
     return launch_solve<nmpc::Centroidal>(h, a, st);
+}
+
+int nmpc_solve_batch(void* handle, int B, const float* x0, const float* yref, int yref_per_stage,
+                     const float* yref_e, const float* params, float* X, float* U, int* status,
+                     float* stats, void* stream) {
+    return nmpc_shift_solve_batch(handle, B, 0, x0, yref, yref_per_stage, yref_e, params, X, U, status, stats, stream);
 }
 
 int nmpc_riccati_batch(void* handle, int Bsz, int nx, int nu, const float* Q, const float* R,
@@ -395,9 +405,7 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= cfg->push_start &&
                      t_now < cfg->push_start + cfg->push_duration) ? dt_replan : 0.0f;
         hipLaunchKernelGGL(nmpc::nmpc_rollout_prepare_kernel, dim3(B), dim3(64), 0, st, r);
-        if (!cold)
-            hipLaunchKernelGGL(nmpc::nmpc_shift_kernel, dim3(B), dim3(256), 0, st, N, h->nx, h->nu,
-                               cfg->nodes_per_replan, X, U);
+        a.shift = cold ? 0 : (cfg->nodes_per_replan > N ? N : cfg->nodes_per_replan);   // warm start folded into the solve
         a.max_sqp = cold ? cfg->max_sqp_first : h->max_sqp;
         a.nlp_tol = cold ? cfg->nlp_tol_first : cfg->nlp_tol;
         const int rc = launch_solve<nmpc::Centroidal>(h, a, st);

@@ -34,6 +34,7 @@ struct SolveArgs {
     int N, B;
     int max_sqp, n_ipm, line_search, yref_per_stage;
     int it;               // SQP iteration this launch pair belongs to
+    int shift;            // warm-start shift folded into this launch pair's reads of X, U (0: none)
     float nlp_tol, mu0, sigma, s_min, gamma, tau_min, rho;
     const float* x0;
     const float* yref;
@@ -48,6 +49,15 @@ struct SolveArgs {
 };
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
+
+// Warm-start shift as an index map (solver.py:304-322, same result as nmpc_shift_kernel): node 0 and
+// the last `shift` nodes of X keep their values, nodes 1..N-shift take those `shift` nodes later; U
+// moves up by `shift` stages and its tail is zero.  With it the shift costs no launch and no pass
+// over memory: the kernels of the first SQP iteration read the previous solution through the map.
+__device__ __forceinline__ int shifted_node(int k, int shift, int N) {
+    return (k >= 1 && k <= N - shift) ? k + shift : k;
+}
+__device__ __forceinline__ bool shifted_stage_valid(int k, int shift, int N) { return k < N - shift; }
 
 // Compact stage images in the workspace (tile strides are multiples of 128 B so an image starts
 // on a cache line).  Images hold logical indices; the slot layout of the tiles (nmpc_tile.hpp)
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     tile_of[1][tid] = stage ? ws + wl.Bt + (size_t)k * G::B_FLOATS : nullptr;
     float x[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)(live ? k : 0) * NX + i];
+    for (int i = 0; i < NX; ++i) x[i] = Xg[(size_t)shifted_node(live ? k : 0, a.shift, N) * NX + i];
     if (live && k == N) {   // terminal gradient and cost
         const float* yre = a.yref_e + (size_t)b * NX;
         float cst = 0.0f;
@@ -293,7 +303,10 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     }
     float u[NU], xn[NX], p[NP > 0 ? NP : 1];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) u[i] = Ug[(size_t)ks * NU + i];
+    for (int i = 0; i < NU; ++i) {
+        const float v = Ug[(size_t)(shifted_stage_valid(ks, a.shift, N) ? ks + a.shift : ks) * NU + i];
+        u[i] = (a.shift == 0 || shifted_stage_valid(ks, a.shift, N)) ? v : 0.0f;
+    }
     const float* pg = a.params + ((size_t)b * (N + 1) + ks) * NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) p[i] = pg[i];
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)(ks + 1) * NX + (i < NX ? i : 0)] : 0.0f;
+            v[i] = (i < NX) ? xn[i < NX ? i : 0] - Xg[(size_t)shifted_node(ks + 1, a.shift, N) * NX + (i < NX ? i : 0)] : 0.0f;
         flush(0, NX, v);
     }
     if (!stage) return;
@@ -450,6 +463,24 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             v[u] = src[e < total ? e : 0];
         }
     };
+    // X and U of the previous solve, read through the warm-start shift (a.shift = 0: identity)
+    auto fetch_x = [&](int base, float (&v)[PRE]) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = base + 64 * u + lane, ec = e < (N + 1) * NX ? e : 0;
+            const int k = ec / NX;
+            v[u] = Xg[ec + (shifted_node(k, a.shift, N) - k) * NX];
+        }
+    };
+    auto fetch_u = [&](int base, float (&v)[PRE]) {
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int e = base + 64 * u + lane, ec = e < N * NU ? e : 0;
+            const bool ok = a.shift == 0 || shifted_stage_valid(ec / NU, a.shift, N);
+            const float t = Ug[ec + (ok ? a.shift * NU : 0)];
+            v[u] = ok ? t : 0.0f;
+        }
+    };
     auto drain = [&](int total, int base, const float (&v)[PRE], auto&& sink) {
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
@@ -471,9 +502,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     const int n_max = n_x > n_c ? n_x : n_c;
     for (int base = 0; base < n_max; base += 64 * PRE) {
         float vx[PRE], vq[PRE], vu[PRE], vr[PRE], vc[PRE];
-        fetch(Xg, n_x, base, vx);
+        fetch_x(base, vx);
         fetch(ws + wl.q, n_x, base, vq);
-        fetch(Ug, n_u, base, vu);
+        fetch_u(base, vu);
         fetch(ws + wl.r, n_u, base, vr);
         fetch(ws + wl.c, n_c, base, vc);
         drain(n_x, base, vx, put_x);

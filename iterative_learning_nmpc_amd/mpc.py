@@ -166,11 +166,11 @@ class BatchedLocomotionMPC:
         if self.first_solve:
             self.X[:] = s.to_device(np.repeat(x[:, None, :], self.n_nodes + 1, axis=1))
             self.U[:] = s.to_device(yref[:, :, 12:])
-        elif self.config_opt.warm_start_sol:
-            s.warm_start_solver(self.X, self.U, self.current_opt_node - s.last_node)
+        # warm start (solver.py:304-322): the shift is folded into the solve
+        shift = 0 if (self.first_solve or not self.config_opt.warm_start_sol) else self.current_opt_node - s.last_node
         s.last_node = self.current_opt_node
         s.solve(s.to_device(x), s.to_device(yref), s.to_device(yref_e), s.to_device(params),
-                self.X, self.U, self.status, self.stats)
+                self.X, self.U, self.status, self.stats, shift=shift)
         return self.X, self.U
 
     # -- simulator-free rollout -------------------------------------------------------------------

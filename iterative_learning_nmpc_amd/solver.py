@@ -127,9 +127,12 @@ class BatchedNmpcSolver:
                                                   _stream_ptr(self.device)), self._h, "nmpc_shift_warm_start")
 
     @time_fn("solve")
-    def solve(self, x0, yref, yref_e, params, X, U, status=None, stats=None
+    def solve(self, x0, yref, yref_e, params, X, U, status=None, stats=None, shift: int = 0
               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Solve B problems in place on (X, U).  Returns (X, U, status[B] int32, stats[B,4])."""
+        """Solve B problems in place on (X, U).  Returns (X, U, status[B] int32, stats[B,4]).
+
+        shift > 0 folds `warm_start_solver(X, U, shift)` into the solve (same result, no extra
+        launch: the first SQP iteration reads X, U through the shift's index map)."""
         B, N = x0.shape[0], self.n_nodes
         self._chk(x0, (B, self.nx), "x0")
         per_stage = yref.dim() == 3
@@ -145,10 +148,10 @@ class BatchedNmpcSolver:
             stats = torch.empty(B, 4, dtype=torch.float32, device=self.device)
         self._chk(status, (B,), "status", torch.int32)
         self._chk(stats, (B, 4), "stats")
-        _lib.check(self.lib.nmpc_solve_batch(
-            self._h, B, _ptr(x0), _ptr(yref), int(per_stage), _ptr(yref_e),
+        _lib.check(self.lib.nmpc_shift_solve_batch(
+            self._h, B, int(shift), _ptr(x0), _ptr(yref), int(per_stage), _ptr(yref_e),
             _ptr(params) if self.np > 0 else None, _ptr(X), _ptr(U), _ptr(status), _ptr(stats),
-            _stream_ptr(self.device)), self._h, "nmpc_solve_batch")
+            _stream_ptr(self.device)), self._h, "nmpc_shift_solve_batch")
         return X, U, status, stats
 
     def riccati(self, Q, R, q, r, A, Bm, d, dx0):

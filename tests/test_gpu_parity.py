@@ -468,3 +468,25 @@ def test_mixed_precision_barrier_product(dev, oracle64):
     print(f"mixed precision: rel-L2 X {eX:.2e} U {eU:.2e}")
     assert np.array_equal(st, sto)
     assert 1e-4 < eX < 0.25 and eU < 0.25, (eX, eU)      # runs, converges to the neighbourhood, is NOT the fp32 path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift,sqp", [(1, 1), (3, 2), (50, 1), (7, 1)])
+def test_fused_shift_solve_equals_shift_then_solve(dev, shift, sqp):
+    """nmpc_shift_solve_batch reads the previous solution through the shift's index map; the result
+    is bit-identical to nmpc_shift_warm_start followed by nmpc_solve_batch."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B = 5
+    w = wl.centroidal_trot(B=B, N=50, seed=31)
+    rng = np.random.default_rng(5)
+    w.X = (w.X + 0.01 * rng.standard_normal(w.X.shape)).astype(np.float32)      # a previous solution with structure
+    w.U = (w.U + 0.5 * rng.standard_normal(w.U.shape)).astype(np.float32)
+    s = _solver(w, B, dev, max_sqp_iter=sqp)
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params")}
+    Xa, Ua = s.to_device(w.X), s.to_device(w.U)
+    s.warm_start_solver(Xa, Ua, shift)
+    s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], Xa, Ua)
+    Xb, Ub = s.to_device(w.X), s.to_device(w.U)
+    _, _, stb, _ = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], Xb, Ub, shift=shift)
+    torch.cuda.synchronize()
+    assert torch.equal(Xa, Xb) and torch.equal(Ua, Ub)
