@@ -93,6 +93,14 @@ int nmpc_set_weights(void *handle, const float *W, const float *W_e, float reg, 
 int nmpc_set_opts(void *handle, int max_sqp_iter, int max_qp_iter, float nlp_tol, float qp_tol,
                   int line_search);
 
+/* Contact patterns of the gait (contact_planner.py:45-118).  The stage sweep has a straight-line
+ * body per contact pattern of the four feet; the default kernel carries those of a trot (the two
+ * diagonal pairs, four-foot stance, flight) and sends every other pattern through a run-time-mask
+ * fallback (same results, ~25 % slower for such stages).  all_patterns = 1 selects the kernel with a
+ * static body for all sixteen patterns: full speed for pace, bound, crawl ..., 2.5 % slower for a
+ * trot.  The host side picks it from the gait configuration. */
+int nmpc_set_contact_patterns(void *handle, int all_patterns);
+
 /* Declared interior-point constants; defaults 10, 0.2, 1, 0.995, 0.1, 1e3. */
 int nmpc_set_ipm(void *handle, float mu0, float sigma, float s_min, float gamma, float tau_min,
                  float merit_rho);

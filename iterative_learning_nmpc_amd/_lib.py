@@ -23,6 +23,7 @@ SIGNATURES = {
     "nmpc_set_model_params": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "nmpc_set_weights": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), c_float, c_float]),
     "nmpc_set_opts": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_int]),
+    "nmpc_set_contact_patterns": (c_int, [c_void_p, c_int]),
     "nmpc_set_ipm": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_float, c_float]),
     "nmpc_shift_warm_start": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_solve_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

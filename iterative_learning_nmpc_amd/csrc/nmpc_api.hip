@@ -27,6 +27,7 @@ struct Handle {
     float* roll = nullptr;   // rollout problem tensors: x0 alias, yref, yref_e, params (B_max sized)
     int n_cu = 256;          // compute units of the device
     int force_variant = 0;   // NMPC_QP_VARIANT: 0 choose by batch size, 1 resident, 2 lean (tests, tuning)
+    int all_patterns = 0;    // nmpc_set_contact_patterns: 1 = kernel with a static stage body per contact pattern
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
@@ -75,20 +76,20 @@ size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
 // Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays while every problem
 // of the batch gets a SIMD of its own, the lean layout (two waves per SIMD) beyond that.
-template <class M, bool LEAN, bool BF16B>
+template <class M, bool LEAN, bool BF16B, bool ALLV>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
     const nmpc::Lds<M, LEAN> L(a.N);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 160 * 1024) return fail(h, NMPC_E_ARG, "horizon too long for the LDS-resident layout");
     if (bytes > 64 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN, BF16B>),
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::nmpc_qp_kernel<M, LEAN, BF16B, ALLV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int shift = a.shift;
     for (int it = 0; it < a.max_sqp; ++it) {
         a.it = it;
         a.shift = (it == 0) ? shift : 0;     // later iterations read their own iterate
         hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
-        hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN, BF16B>), dim3(a.B), dim3(64), bytes, st, a);
+        hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN, BF16B, ALLV>), dim3(a.B), dim3(64), bytes, st, a);
     }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
@@ -102,9 +103,17 @@ int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     const size_t resident_bytes = (size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float);
     const long long resident_waves = resident_bytes <= 160 * 1024 ? (long long)h->n_cu * (long long)((160 * 1024) / resident_bytes) : 0;
     const bool lean = h->force_variant ? (h->force_variant > 1) : (a.B > resident_waves);
+    // all static variants only where the model has more than its short list and the caller asked for them
+    if constexpr (M::N_STATIC_MASKS > 4) {
+        if (h->all_patterns) {
+            if (h->dims.precision == 1)
+                return lean ? launch_qp<M, true, true, true>(h, a, st, lin_blocks) : launch_qp<M, false, true, true>(h, a, st, lin_blocks);
+            return lean ? launch_qp<M, true, false, true>(h, a, st, lin_blocks) : launch_qp<M, false, false, true>(h, a, st, lin_blocks);
+        }
+    }
     if (h->dims.precision == 1)
-        return lean ? launch_qp<M, true, true>(h, a, st, lin_blocks) : launch_qp<M, false, true>(h, a, st, lin_blocks);
-    return lean ? launch_qp<M, true, false>(h, a, st, lin_blocks) : launch_qp<M, false, false>(h, a, st, lin_blocks);
+        return lean ? launch_qp<M, true, true, false>(h, a, st, lin_blocks) : launch_qp<M, false, true, false>(h, a, st, lin_blocks);
+    return lean ? launch_qp<M, true, false, false>(h, a, st, lin_blocks) : launch_qp<M, false, false, false>(h, a, st, lin_blocks);
 }
 
 template <class M>
@@ -254,6 +263,13 @@ int nmpc_set_opts(void* handle, int max_sqp_iter, int max_qp_iter, float nlp_tol
     if (max_sqp_iter < 1 || max_qp_iter < 0) return fail(h, NMPC_E_ARG, "iteration counts out of range");
     h->max_sqp = max_sqp_iter; h->n_ipm = max_qp_iter;
     h->nlp_tol = nlp_tol; h->qp_tol = qp_tol; h->line_search = line_search ? 1 : 0;
+    return NMPC_OK;
+}
+
+int nmpc_set_contact_patterns(void* handle, int all_patterns) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    h->all_patterns = all_patterns ? 1 : 0;
     return NMPC_OK;
 }
 

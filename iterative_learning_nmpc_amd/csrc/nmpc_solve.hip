@@ -247,7 +247,7 @@ struct Lds {
         gvt = o; o += N * TS;
         act = o; o += round4(NS);
         umk = o; o += round4(NS);
-        conv = o; o += CONV_TILES * CTILE;
+        conv = o; o += CONV_FLOATS;
         total = o;
     }
 };
@@ -398,7 +398,11 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // QP + step of one SQP iteration: one problem per wavefront.
 // LEAN: LDS layout variant (Lds).  BF16B: the barrier product Gs'[Gs | vt] on the bf16 matrix pipe
 // (nmpc_dims.precision = 1, BASELINE configs[4]); everything else stays fp32.
-template <class M, bool LEAN, bool BF16B>
+// ALLV: the stage loop dispatches over every static variant the model lists (all contact patterns);
+// otherwise over the model's short list (common_variant) with the run-time fallback for the rest.
+// Two kernels rather than one loop with everything: measured, the mere presence of the other
+// variants in the kernel costs the common ones 2.5 % (code layout, register allocation).
+template <class M, bool LEAN, bool BF16B, bool ALLV>
 __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
@@ -520,7 +524,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
         if (k < N) {
             const unsigned am = reinterpret_cast<const unsigned*>(ws + wl.act)[k];
             actm[k] = am;
-            umask[k] = reinterpret_cast<const unsigned*>(ws + wl.umk)[k];
+            // coupling mask of the stage, with the index of its static variant (+1; 0 = none) on top:
+            // the stage loop then dispatches on one shift instead of recomputing the index every stage
+            const unsigned um = reinterpret_cast<const unsigned*>(ws + wl.umk)[k];
+            umask[k] = um | ((unsigned)(M::static_index(um) + 1) << 16);
             nact_l += __popc(am);
             mu_l += a.mu0 * (float)__popc(am);      // s * (mu0 / s) per active row
         }
@@ -536,9 +543,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
     // lane's four tile registers takes (a clamped LDS feature index and a 0/1 mask), so that the
     // cost tiles of a stage are built with unconditional loads and selects (no branches)
     SweepLane sl;
-    sl.init(conv, lane, HS);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sl.rs_free[j] = a.rs_free[j];
+    sl.init(conv, lane, HS, a.rs_free);
     f32x4 Qc, Rc, Gc;            // constant parts: diag(Wx)+reg, diag(Wu)+reg, constraint matrix G
     bool qm[4], rm[4];           // masks: the register takes an element of q / r
 #pragma unroll
@@ -723,15 +728,39 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
                     f32x4 Kk, Acl;
                     NextCost sh = next_cost(kn);
                     auto run = [&](auto mask_tag) {
-                        return backward_stage<NU, decltype(mask_tag)::value, true>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
-                                                                             cm, Kk, Acl, sh SST_PASS);
+                        return backward_stage<NU, decltype(mask_tag)::value, true, ALLV>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
+                                                                             cm & 0xFFFFu, Kk, Acl, sh SST_PASS);
                     };
-                    bool ok;
-                    if (cm == M::static_mask(0)) ok = run(std::integral_constant<unsigned, M::static_mask(0)>{});
-                    else if (M::N_STATIC_MASKS > 1 && cm == M::static_mask(1)) ok = run(std::integral_constant<unsigned, M::static_mask(1)>{});
-                    else if (M::N_STATIC_MASKS > 2 && cm == M::static_mask(2)) ok = run(std::integral_constant<unsigned, M::static_mask(2)>{});
-                    else if (M::N_STATIC_MASKS > 3 && cm == M::static_mask(3)) ok = run(std::integral_constant<unsigned, M::static_mask(3)>{});
-                    else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
+                    bool ok = true;
+                    // one static variant per mask: the model's short list as a chain (ALLV = false), or
+                    // every listed variant through a decision tree; any other mask takes the run-time fallback
+#define NMPC_VARIANT(I)                                                                                   \
+    case I:                                                                                               \
+        if constexpr (I < M::N_STATIC_MASKS)                                                              \
+            ok = run(std::integral_constant<unsigned, M::static_mask(I < M::N_STATIC_MASKS ? I : 0)>{}); \
+        else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});                                  \
+        break;
+#define NMPC_COMMON(J) (M::common_variant(J) >= 0 && vi == M::common_variant(J))
+#define NMPC_RUN_COMMON(J) run(std::integral_constant<unsigned, M::static_mask(M::common_variant(J) >= 0 ? M::common_variant(J) : 0)>{})
+                    const int vi = (int)(cm >> 16) - 1;
+                    if constexpr (!ALLV) {
+                        if (NMPC_COMMON(0)) ok = NMPC_RUN_COMMON(0);
+                        else if (NMPC_COMMON(1)) ok = NMPC_RUN_COMMON(1);
+                        else if (NMPC_COMMON(2)) ok = NMPC_RUN_COMMON(2);
+                        else if (NMPC_COMMON(3)) ok = NMPC_RUN_COMMON(3);
+                        else ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
+                    } else {
+                        switch (vi) {
+                            NMPC_VARIANT(0) NMPC_VARIANT(1) NMPC_VARIANT(2) NMPC_VARIANT(3)
+                            NMPC_VARIANT(4) NMPC_VARIANT(5) NMPC_VARIANT(6) NMPC_VARIANT(7)
+                            NMPC_VARIANT(8) NMPC_VARIANT(9) NMPC_VARIANT(10) NMPC_VARIANT(11)
+                            NMPC_VARIANT(12) NMPC_VARIANT(13) NMPC_VARIANT(14) NMPC_VARIANT(15)
+                            default: ok = run(std::integral_constant<unsigned, DYNAMIC_MASK>{});
+                        }
+                    }
+#undef NMPC_VARIANT
+#undef NMPC_COMMON
+#undef NMPC_RUN_COMMON
                     qp_ok = ok && qp_ok;
                     ks.store(Kt, Kk);      // gain tiles of this stage, read by the forward sweep
                     cs.store(Ct, Acl);

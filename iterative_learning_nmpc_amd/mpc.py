@@ -82,6 +82,7 @@ class BatchedLocomotionMPC:
 
         self.mp = model_params(dt=self.dt_nodes, mass=mass, Ixx=inertia[0], Iyy=inertia[1], Izz=inertia[2])
         self.solver = BatchedNmpcSolver(MODEL_CENTROIDAL, self.n_nodes, self.batch, device, compute_timings)
+        self.solver.set_contact_patterns(gait_sequence=self.contact_planner.gait_sequence)   # kernel by gait
         self.device = self.solver.device
         self.solver.set_model_params(self.mp)
         W = np.concatenate([self.config_cost.W_base, self.config_cost.W_cnt_f_reg.ravel()])

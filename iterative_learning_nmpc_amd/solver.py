@@ -84,6 +84,20 @@ class BatchedNmpcSolver:
     def set_line_search(self, on: bool):
         self._opts["line_search"] = int(bool(on)); self._push_opts()
 
+    # contact patterns of a trot: diagonal pairs (feet 0+3, 1+2), four-foot stance, flight -- as 4-bit stance flags
+    COMMON_CONTACT_PATTERNS = frozenset({0b1001, 0b0110, 0b1111, 0b0000})
+
+    def set_contact_patterns(self, all_patterns: bool = None, gait_sequence=None):
+        """Choose the kernel by the gait: `gait_sequence[4, nodes]` (0/1 stance flags, contact_planner.py)
+        whose patterns all belong to a trot keeps the default kernel; any other pattern selects the
+        kernel with a static stage body for every contact pattern (see include/nmpc.h)."""
+        if all_patterns is None:
+            g = np.asarray(gait_sequence).astype(np.int64)
+            pats = set((g[0] | (g[1] << 1) | (g[2] << 2) | (g[3] << 3)).tolist())
+            all_patterns = not pats <= self.COMMON_CONTACT_PATTERNS
+        _lib.check(self.lib.nmpc_set_contact_patterns(self._h, int(bool(all_patterns))), self._h, "nmpc_set_contact_patterns")
+        return bool(all_patterns)
+
     def set_ipm(self, mu0=10.0, sigma=0.2, s_min=1.0, gamma=0.995, tau_min=0.1, merit_rho=1e3):
         _lib.check(self.lib.nmpc_set_ipm(self._h, mu0, sigma, s_min, gamma, tau_min, merit_rho),
                    self._h, "nmpc_set_ipm")

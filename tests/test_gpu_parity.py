@@ -490,3 +490,46 @@ def test_fused_shift_solve_equals_shift_then_solve(dev, shift, sqp):
     _, _, stb, _ = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], Xb, Ub, shift=shift)
     torch.cuda.synchronize()
     assert torch.equal(Xa, Xb) and torch.equal(Ua, Ub)
+
+
+@pytest.mark.gpu
+def test_all_contact_patterns_kernel_matches_default_and_oracle(dev, oracle64):
+    """Random contact patterns per stage (every subset of the four feet occurs): the default kernel
+    (static bodies for the trot patterns, run-time-mask fallback for the rest) and the kernel with a
+    static body per pattern (nmpc_set_contact_patterns) solve the same problems; both match the oracle."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B, N = 24, 50
+    w = wl.centroidal_trot(B=B, N=N, seed=23)
+    rng = np.random.default_rng(7)
+    flags = rng.integers(0, 2, size=(B, N + 1, 4)).astype(np.float32)
+    flags[:, :, :][flags.sum(-1) == 0] = np.array([1, 0, 0, 1], np.float32)        # keep some support most of the time
+    flags[:, ::7] = 0.0                                                              # ... and some flight stages
+    w.params[:, :, 0:4] = flags
+    n_st = np.maximum(flags[:, :N].sum(-1, keepdims=True), 1.0)
+    fz = (-w.mp[5] * w.mp[1]) / n_st                                                 # weight shared by the stance feet
+    for i in range(4):
+        w.yref[:, :, 12 + 3 * i: 14 + 3 * i] = 0.0
+        w.yref[:, :, 14 + 3 * i] = (fz[..., 0] * flags[:, :N, i]).astype(np.float32)
+    w.U[:] = w.yref[:, :, 12:]
+    assert len(np.unique((flags[:, :N] * np.array([1, 2, 4, 8])).sum(-1))) == 16
+    out = {}
+    for allp in (False, True):
+        s = _solver(w, B, dev)
+        assert s.set_contact_patterns(all_patterns=allp) == allp
+        out[allp] = _gpu_solve(s, w)
+    Xo, Uo, sto, _ = _oracle_solve(oracle64, w)
+    for allp in (False, True):
+        X, U, st, _ = out[allp]
+        assert np.array_equal(st, sto)
+        assert rel(X, Xo) < 3e-5 and rel(U, Uo) < 3e-5, (allp, rel(X, Xo), rel(U, Uo))
+    assert rel(out[True][0], out[False][0]) < 3e-5
+
+
+def test_contact_pattern_choice_from_gait_table():
+    """Host side: a trot keeps the default kernel, a pace or a crawl asks for all patterns."""
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    common = BatchedNmpcSolver.COMMON_CONTACT_PATTERNS
+    pat = lambda g: set((np.asarray(g)[0] | (np.asarray(g)[1] << 1) | (np.asarray(g)[2] << 2) | (np.asarray(g)[3] << 3)).tolist())
+    trot = np.array([[1, 1, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1], [1, 1, 0, 0]])
+    pace = np.array([[1, 1, 0, 0], [0, 0, 1, 1], [1, 1, 0, 0], [0, 0, 1, 1]])
+    assert pat(trot) <= common and not pat(pace) <= common
