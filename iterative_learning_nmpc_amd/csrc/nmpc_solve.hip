@@ -815,9 +815,17 @@ __global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
             // refill comes after the last use, so old and new value share registers and the loop
             // carries no copies -- a copy of fresh load data would put a full wait into every stage)
             auto fwd_stage = [&](int k, f32x4 (&slot)[RQ4]) {
-                float acc = slot[0][HS];          // times dx~[HS] = 1
+                // four accumulator chains: a dependent v_fmac issues only every ~11 cycles, four chains
+                // keep the 4-cycle issue rate (tools/ubench/ubench_dpp.hip).  asm: left to itself the
+                // compiler re-associates the sum and, worse, re-schedules the ring refills around it.
+                float acc = slot[0][HS], acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;   // slot HS: times dx~[HS] = 1
 #pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fmaf(slot[slot_of(i) >> 2][slot_of(i) & 3], vs[i], acc);
+                for (int i = 0; i < NX; ++i) {
+                    const float e = slot[slot_of(i) >> 2][slot_of(i) & 3];
+                    float& ac = (i & 3) == 0 ? acc : (i & 3) == 1 ? acc1 : (i & 3) == 2 ? acc2 : acc3;
+                    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ac) : "s"(vs[i]), "v"(e));
+                }
+                acc = (acc + acc1) + (acc2 + acc3);
                 load_row(rowoff < rowlast ? rowoff : rowlast, slot);
                 rowoff += rowstep;
                 dst[k * dstep] = acc;
