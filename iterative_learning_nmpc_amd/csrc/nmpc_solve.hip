@@ -7,14 +7,17 @@
 //                          register budget, no cross-lane traffic)
 //   nmpc_qp_kernel         one problem per wavefront: interior-point loop of Riccati sweeps
 //        phase R (serial stages)  backward sweep on 16x16 tiles: MFMA products + readlane LDL'
-//        phase F (serial stages)  rollout of the closed loop (MFMA mat-vec)
+//        phase F (serial stages)  rollout of the closed loop (row-per-lane VALU mat-vec)
 //        phase I (lane = stage)   interior-point step: slacks, multipliers, fraction to boundary
 //        phase S (lane = stage)   step (optionally l1-merit backtracking), status, write back
 // Splitting the linearisation off keeps the sweep kernel's register allocation small (the
 // Jacobian code wants hundreds of VGPRs; fused, it forced the MFMA accumulators of the sweeps
 // through AGPR<->VGPR copies and pinned the kernel at one wave per SIMD).
-// Stage matrices A~,B~,K~',Acl~' live in an HBM/L2 workspace as 1 KiB tile images; trajectories,
-// gradients and IPM state of a problem live in LDS (~38 KB at N=50) inside nmpc_qp_kernel.
+// Stage matrices A~, B~, K~, Acl~ live in an HBM/L2 workspace as compact images (640-768 B);
+// trajectories, gradients and IPM state of a problem live in LDS (39.6 KB at N = 50) inside
+// nmpc_qp_kernel -- or, in its lean variant for large batches, partly in the workspace (Lds).
+// Kernel variants (template flags): LDS layout, precision of the barrier product, set of contact
+// patterns with a static stage body.  DESIGN.md 5 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -251,14 +254,6 @@ struct Lds {
         total = o;
     }
 };
-
-// write one column (rows 0..15) of a column-major tile image
-__device__ __forceinline__ void store_col16(float* tile, int c, const float (&v)[16], int nquads) {
-    f32x4* p = reinterpret_cast<f32x4*>(tile + c * TS);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nquads) p[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-}
 
 // ------------------------------------------------------------------------------------------------
 // Linearisation: thread t <-> (problem b, stage k), k = N is the terminal stage.

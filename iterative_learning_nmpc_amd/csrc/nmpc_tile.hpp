@@ -111,17 +111,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ t, int lane, f32x
     const int q = lane >> 4, c = lane & 15;
     *reinterpret_cast<f32x4*>(t + c * TS + 4 * q) = v;
 }
-// accumulator layout of the TRANSPOSE of the stored tile: 4 dword loads, each 64 B contiguous
-__device__ __forceinline__ f32x4 load_tile_t(const float* __restrict__ t, int lane) {
-    const int q = lane >> 4, c = lane & 15;
-    f32x4 v;
-    v[0] = t[(4 * q + 0) * TS + c];
-    v[1] = t[(4 * q + 1) * TS + c];
-    v[2] = t[(4 * q + 2) * TS + c];
-    v[3] = t[(4 * q + 3) * TS + c];
-    return v;
-}
-
 // transposed image of an accumulator-layout tile: 4 dword stores (64 B runs), so that a later
 // load_tile() of the same memory yields the accumulator layout of the TRANSPOSE in one 16 B load
 __device__ __forceinline__ void store_tile_t(float* __restrict__ t, int lane, f32x4 v) {
