@@ -533,3 +533,50 @@ def test_contact_pattern_choice_from_gait_table():
     trot = np.array([[1, 1, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1], [1, 1, 0, 0]])
     pace = np.array([[1, 1, 0, 0], [0, 0, 1, 1], [1, 1, 0, 0], [0, 0, 1, 1]])
     assert pat(trot) <= common and not pat(pace) <= common
+
+
+@pytest.mark.gpu
+def test_device_rollout_is_the_same_under_every_kernel_variant(dev, monkeypatch):
+    """Device-resident rollouts (cold start, warm replans with the folded shift, push) through the lean
+    LDS layout and through the all-contact-patterns kernel reproduce the default kernel's states:
+    bit for bit for the layout (same arithmetic), to rounding for the pattern set (same stage bodies
+    for a trot, other code only around them)."""
+    from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC
+    B, T = 5, 0.32
+    rng = np.random.default_rng(11)
+    x0 = np.zeros((B, 12)); x0[:, 2] = 0.3
+    x0[:, :2] = rng.normal(0, 0.03, (B, 2))
+    push = dict(start=0.08, duration=0.08, force=rng.uniform(-1, 1, (B, 3)) * 40.0)
+
+    def roll(variant, all_patterns):
+        if variant: monkeypatch.setenv("NMPC_QP_VARIANT", variant)
+        else: monkeypatch.delenv("NMPC_QP_VARIANT", raising=False)
+        mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+        assert mpc.solver.set_contact_patterns(gait_sequence=mpc.contact_planner.gait_sequence) is False   # a trot
+        mpc.solver.set_contact_patterns(all_patterns=all_patterns)
+        mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+        S, _ = mpc.open_loop_device(x0, T, push)
+        torch.cuda.synchronize()
+        assert int(mpc.failed.sum().item()) == 0
+        return S.cpu().numpy()
+
+    ref = roll(None, False)
+    assert np.array_equal(roll("lean", False), ref)
+    assert np.array_equal(roll("resident", False), ref)
+    assert rel(roll(None, True), ref) < 2e-5
+
+
+@pytest.mark.gpu
+def test_option_argument_errors(dev):
+    from iterative_learning_nmpc_amd import workloads as wl, _lib
+    w = wl.centroidal_trot(B=2, N=50, seed=0)
+    s = _solver(w, 2, dev)
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+    with pytest.raises(_lib.NmpcError, match="negative shift"):
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], shift=-1)
+    s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], shift=10 ** 6)     # clamps to N: U becomes the zero tail
+    torch.cuda.synchronize()
+    assert s.lib.nmpc_set_contact_patterns(None, 1) != 0
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    with pytest.raises(_lib.NmpcError):
+        BatchedNmpcSolver(1, 50, 2, dev, precision=7)
