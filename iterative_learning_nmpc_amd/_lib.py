@@ -34,9 +34,23 @@ SIGNATURES = {
     "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p]),
     "nmpc_rollout_batch": (c_int, [c_void_p, c_int, c_void_p] + [c_void_p] * 14),
+    # include/nmpc_policy.h
+    "nmpc_policy_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "nmpc_policy_destroy": (None, [c_void_p]),
+    "nmpc_policy_last_error": (ctypes.c_char_p, [c_void_p]),
+    "nmpc_policy_param_count": (ctypes.c_size_t, [c_void_p]),
+    "nmpc_policy_set_params": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_policy_get_params": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_policy_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nmpc_policy_train_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }
+
+
+class NmpcPolicyDims(ctypes.Structure):
+    _fields_ = [("n_in", c_int), ("n_out", c_int), ("n_hidden", c_int), ("hidden", c_int),
+                ("batch_norm", c_int), ("batch_max", c_int)]
 
 
 class NmpcRolloutCfg(ctypes.Structure):

@@ -20,7 +20,7 @@ def lib():
 
 def test_header_symbols_are_exported_and_bound(lib):
     from iterative_learning_nmpc_amd import _lib
-    header = open(os.path.join(ROOT, "include", "nmpc.h")).read()
+    header = open(os.path.join(ROOT, "include", "nmpc.h")).read() + open(os.path.join(ROOT, "include", "nmpc_policy.h")).read()
     declared = set(re.findall(r"\b(nmpc_[a-z_]+)\s*\(", header))
     assert declared, "no declarations found"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)

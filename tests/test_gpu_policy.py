@@ -1,0 +1,115 @@
+"""GPU parity of the learning update (include/nmpc_policy.h) against the numpy oracle and the
+vectors generated from the reference's own network module.  fp32 throughout; tolerances are the
+fp32-vs-fp64 floor of sums over 512 terms (1e-5 relative on predictions and gradients-in-effect)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _pair(n_in, n_out, L, hidden, bn, batch_max, seed=0):
+    """A DevicePolicy and an fp64 oracle with the same (random, non-trivial) parameters."""
+    from iterative_learning_nmpc_amd.policy import DevicePolicy
+    from oracle.policy_oracle import PolicyOracle
+    pol = DevicePolicy(n_in, n_out, L, hidden, bn, batch_max=batch_max, device="cuda:0", seed=seed)
+    o = PolicyOracle(n_in, n_out, L, hidden, bn, np.float64)
+    rng = np.random.default_rng(seed + 1)
+    theta, rm, rv = (t.cpu().numpy().astype(np.float64) for t in pol.get_parameters())
+    for name, shape, off in pol.items:                   # biases, gamma, beta away from their trivial start values
+        n = int(np.prod(shape))
+        if name.endswith(".b") or name.endswith(".beta"):
+            theta[off:off + n] = 0.1 * rng.standard_normal(n)
+        if name.endswith(".gamma"):
+            theta[off:off + n] = 1.0 + 0.1 * rng.standard_normal(n)
+    rm = 0.1 * rng.standard_normal(rm.shape); rv = 1.0 + 0.2 * rng.random(rv.shape)
+    pol.set_parameters(theta, rm, rv)
+    o.theta[:] = theta; o.running_mean[:] = rm; o.running_var[:] = rv
+    return pol, o
+
+
+@pytest.mark.parametrize("name", ["bn", "plain"])
+def test_policy_matches_reference_vectors(name):
+    """The reference's own module (CPU fp32): train-mode predictions and losses of three Adam steps,
+    final parameters, eval-mode prediction."""
+    from iterative_learning_nmpc_amd.policy import DevicePolicy
+    g = np.load(os.path.join(GOLD, f"policy_{name}.npz"))
+    n_in, n_out, L, hidden, bn, batch, steps = [int(v) for v in g["dims"]]
+    pol = DevicePolicy(n_in, n_out, L, hidden, bool(bn), batch_max=batch, seed=None)
+    pol.load_state_dict({k[5:]: g[k] for k in g.files if k.startswith("init.")})
+    dev = pol.device
+    for s in range(steps):
+        loss, pred = pol.train_step(torch.tensor(g["X"][s], device=dev), torch.tensor(g["Y"][s], device=dev),
+                                    float(g["lr"]), return_pred=True)
+        assert abs(loss.item() - g["train_loss"][s]) < 5e-6
+        assert np.abs(pred.cpu().numpy() - g["train_pred"][s]).max() < 5e-5
+    ref = DevicePolicy(n_in, n_out, L, hidden, bool(bn), batch_max=batch, seed=None)
+    ref.load_state_dict({k[6:]: g[k] for k in g.files if k.startswith("final.")})
+    th, rm, rv = (t.cpu().numpy() for t in pol.get_parameters())
+    th_ref, rm_ref, rv_ref = (t.cpu().numpy() for t in ref.get_parameters())
+    noise = np.zeros(pol.n_theta, bool)                  # biases in front of a BatchNorm: exact gradient zero, Adam moves them on noise
+    if bn:
+        for n_, s_, off in pol.items:
+            if n_.endswith(".b") and int(n_.split(".")[1]) < L:
+                noise[off:off + int(np.prod(s_))] = True
+    d = np.abs(th - th_ref)
+    assert d[~noise].max() < 5e-5 and (not noise.any() or d[noise].max() <= 2.01 * steps * float(g["lr"]))
+    if bn:
+        assert np.abs(rv - rv_ref).max() < 1e-5 and np.abs(rm - rm_ref).max() < 0.1 * 3 * steps * float(g["lr"])
+    assert np.abs(ref.forward(torch.tensor(g["X"][0], device=dev)).cpu().numpy() - g["eval_pred"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("n_in,n_out,L,hidden,bn,B", [(47, 12, 3, 512, True, 256), (47, 12, 3, 512, True, 1000),
+                                                       (5, 3, 1, 7, True, 2), (9, 4, 2, 65, False, 33),
+                                                       (130, 70, 2, 100, True, 129)])
+def test_policy_forward_and_train_step_match_oracle(n_in, n_out, L, hidden, bn, B):
+    """Full-size network of the reference's configuration (47 -> 3 x 512 -> 12, BatchNorm, batch 256 / 1000)
+    and ragged shapes (tile remainders in every GEMM dimension)."""
+    pol, o = _pair(n_in, n_out, L, hidden, bn, batch_max=B + 3)
+    rng = np.random.default_rng(5)
+    dev = pol.device
+    X = rng.standard_normal((B, n_in)); Y = rng.standard_normal((B, n_out))
+    y_eval = pol.forward(torch.tensor(X, dtype=torch.float32, device=dev)).cpu().numpy()
+    assert rel(y_eval, o.forward(X, train=False)) < 1e-5
+    for step in range(2):
+        loss, pred = pol.train_step(torch.tensor(X, dtype=torch.float32, device=dev),
+                                    torch.tensor(Y, dtype=torch.float32, device=dev), 1e-3, return_pred=True)
+        lo, po, go = o.train_step(X, Y, 1e-3)
+        # step 0 is a pure fp32-vs-fp64 comparison; step 1 runs on parameters that Adam moved by ~lr in
+        # the direction of sign(gradient), which is rounding noise wherever the exact gradient is ~0
+        assert abs(loss.item() - lo) < (1e-5 if step == 0 else 2e-3) * max(1.0, lo)
+        assert rel(pred.cpu().numpy(), po) < (2e-5 if step == 0 else 3e-3)
+        if step == 0:
+            th, rm, rv = (t.cpu().numpy() for t in pol.get_parameters())
+            d = np.abs(th - o.theta)
+            strong = np.abs(go) > 1e-2 * np.abs(go).max()      # an fp32 gradient there is good to ~1e-4 relative -> lr x that
+            assert d[strong].max() < 2e-5, d[strong].max()
+            assert d.max() <= 2.01e-3                           # everything else moved by at most lr
+            if bn:
+                assert rel(rv, o.running_var) < 1e-5 and rel(rm, o.running_mean) < 1e-5
+    # the updated network still agrees in eval mode (to the Adam noise explained above)
+    assert rel(pol.forward(torch.tensor(X, dtype=torch.float32, device=dev)).cpu().numpy(), o.forward(X, train=False)) < 1e-2
+
+
+def test_policy_argument_errors():
+    from iterative_learning_nmpc_amd import _lib
+    from iterative_learning_nmpc_amd.policy import DevicePolicy
+    with pytest.raises(_lib.NmpcError):
+        DevicePolicy(0, 3, 1, 8, True)
+    pol = DevicePolicy(4, 3, 1, 8, True, batch_max=8)
+    x = torch.zeros(9, 4, device=pol.device); y = torch.zeros(9, 3, device=pol.device)
+    with pytest.raises(_lib.NmpcError, match="batch_max"):
+        pol.forward(x)
+    with pytest.raises(_lib.NmpcError):
+        pol.train_step(x[:1].contiguous(), y[:1].contiguous())          # BatchNorm needs two rows
+    with pytest.raises(_lib.NmpcError):
+        pol.train_step(x[:4].contiguous(), y[:4].contiguous(), lr=0.0)
