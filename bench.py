@@ -134,6 +134,66 @@ def rollout_mode(a, world, rank, dev, dist):
                        "failed_rollouts": int(mpc.failed.sum().item())}}), flush=True)
 
 
+def policy_mode(a, world, rank, dev, dist):
+    """Learning update: training steps of the reference's policy network
+    (47 -> 3 x 512 -> 12, BatchNorm, L1 loss, Adam; cfgs/iter_locosafedagger.yaml:52-58) on a batch of
+    a.policy samples per GPU; every rank trains its own replica on its own shard (the reference trains
+    on one device -- no gradient exchange is part of this path)."""
+    from iterative_learning_nmpc_amd.policy import DevicePolicy
+    B, n_in, n_out, L, H = a.policy, 47, 12, 3, 512
+    pol = DevicePolicy(n_in, n_out, L, H, True, batch_max=B, device=dev, seed=rank)
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    X = torch.randn(B, n_in, generator=g).to(dev); Y = torch.randn(B, n_out, generator=g).to(dev)
+    for _ in range(a.warmup):
+        pol.train_step(X, Y, 1e-3)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        loss = pol.train_step(X, Y, 1e-3)
+    e1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    ms = e0.elapsed_time(e1) / a.steps
+    macs = n_in * H + (L - 1) * H * H + H * n_out
+    flops = 2.0 * B * (3 * macs - n_in * H)            # forward, weight gradient, data gradient (not for the input layer)
+    nbytes = 4.0 * (B * (n_in + 2 * n_out) + 4 * (macs + (L * 3 + 1) * H))   # batch in/out + theta, grad, m, v once each
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle.policy_oracle import PolicyOracle      # the checker, timed as the reported CPU baseline
+        o = PolicyOracle(n_in, n_out, L, H, True, np.float32)
+        th, rm, rv = (t.cpu().numpy() for t in pol.get_parameters())
+        o.theta[:] = th; o.running_mean[:] = rm; o.running_var[:] = rv
+        Xh, Yh = X.cpu().numpy(), Y.cpu().numpy()
+        o.train_step(Xh, Yh, 1e-3)
+        n_rep, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 10.0:
+            o.train_step(Xh, Yh, 1e-3); n_rep += 1
+        cpu = {"value": n_rep * B / (time.perf_counter() - t1), "unit": "samples/s", "cores": host_cores(), "kind": "port",
+               "sample": f"{n_rep} training steps of the same batch, fp32 numpy oracle (BLAS threads as granted)"}
+    if rank == 0:
+        tf = flops / (ms * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "policy training samples/sec (47-3x512-12 MLP, BatchNorm, L1, Adam)",
+            "value": world * B * a.steps / el, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"learning update: batch {B}/GPU, one Adam step per step", "final_loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "kernel": "gemm_kernel (8 of the 27 launches of a step)",
+                         "kernel_ms": ms, "flops_per_step": flops, "bytes_per_step": nbytes},
+            "cpu_baseline": cpu}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +208,8 @@ def main():
     ap.add_argument("--rollouts", type=int, default=0,
                     help="extra mode (not the headline metric): B rollouts per GPU of 2 s (50 replans) fully "
                          "on the device, tracking error vs the nominal rollout, all-gather over the ranks")
+    ap.add_argument("--policy", type=int, default=0,
+                    help="extra mode (not the headline metric): training steps of the policy network on a batch of this size")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,8 +225,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if a.rollouts:
-        rollout_mode(a, world, rank, dev, dist)
+    if a.rollouts or a.policy:
+        (rollout_mode if a.rollouts else policy_mode)(a, world, rank, dev, dist)
         if dist:
             dist.destroy_process_group()
         return

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <string>
 
@@ -32,11 +33,15 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 // reads); a wave owns a 32 x 32 quarter and runs v_mfma_f32_32x32x2_f32: lane (h, i) supplies row
 // 32w + i and the k slots 8h .. 8h+7 of the slice as two 16 B reads per operand (the order of the
 // k terms is irrelevant as long as A and B agree), eight MFMAs per slice.
-// Loads are guarded element-wise (K = 47, N = 12 ... are not tile multiples; rows of X are not 16 B
-// aligned), which is good enough: these GEMMs are 0.5 GFLOP each.
+// VEC = false: loads are guarded element-wise (K = 47, N = 12 ... are not tile multiples; rows of X
+// are not 16 B aligned).  VEC = true (M, N multiples of 64, K of 16 x gridDim.z, leading dimensions
+// multiples of 4): 16 B global loads without guards, the next K slice prefetched into registers while
+// the current one is multiplied.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
+// batch and have only 64 output tiles): the partial products are added to C with float atomics, C
+// zeroed by the caller.
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                    int ldc, const float* __restrict__ bias) {
@@ -46,32 +51,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = 32 * (w >> 1), wn = 32 * (w & 1);
     const int h = lane >> 5, li = lane & 31;
+    const int kper = K / (int)gridDim.z;                          // gridDim.z > 1 only with VEC
+    const int kbeg = blockIdx.z * kper, kend = (gridDim.z > 1) ? kbeg + kper : K;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        // global -> LDS: 64 x 16 elements per operand, four per thread
+    // this thread's four elements of a 64 x 16 operand slice: (row, kk .. kk+3) if k is contiguous in
+    // memory, (row .. row+3, kk) if the rows are
+    const int a_row = TA ? 4 * (tid & 15) : tid >> 2, a_kk = TA ? tid >> 4 : 4 * (tid & 3);
+    const int b_row = TB ? 4 * (tid & 15) : tid >> 2, b_kk = TB ? tid >> 4 : 4 * (tid & 3);
+    auto load_a = [&](int k0) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VEC) {
+            v = TA ? *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + a_kk) * lda + m0 + a_row)
+                   : *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + a_row) * lda + k0 + a_kk);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int row, kk;
-            if (!TA) { row = tid >> 2; kk = 4 * (tid & 3) + e; }          // k contiguous in memory
-            else { kk = tid >> 4; row = 4 * (tid & 15) + e; }             // row contiguous in memory
-            const int m = m0 + row, k = k0 + kk;
-            float v = 0.0f;
-            if (m < M && k < K) v = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
-            As[row * LDT + kk] = v;
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + a_row + (TA ? e : 0), k = k0 + a_kk + (TA ? 0 : e);
+                if (m < M && k < K) v[e] = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+            }
         }
+        return v;
+    };
+    auto load_b = [&](int k0) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VEC) {
+            v = TB ? *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + b_kk) * ldb + n0 + b_row)
+                   : *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + b_row) * ldb + k0 + b_kk);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int row, kk;
-            if (!TB) { row = tid >> 2; kk = 4 * (tid & 3) + e; }
-            else { kk = tid >> 4; row = 4 * (tid & 15) + e; }
-            const int n = n0 + row, k = k0 + kk;
-            float v = 0.0f;
-            if (n < N && k < K) v = TB ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
-            Bs[row * LDT + kk] = v;
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + b_row + (TB ? e : 0), k = k0 + b_kk + (TB ? 0 : e);
+                if (n < N && k < K) v[e] = TB ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
+            }
         }
+        return v;
+    };
+    auto stage = [&](f32x4 va, f32x4 vb) {
+        if (TA) { for (int e = 0; e < 4; ++e) As[(a_row + e) * LDT + a_kk] = va[e]; }
+        else *reinterpret_cast<f32x4*>(As + a_row * LDT + a_kk) = va;
+        if (TB) { for (int e = 0; e < 4; ++e) Bs[(b_row + e) * LDT + b_kk] = vb[e]; }
+        else *reinterpret_cast<f32x4*>(Bs + b_row * LDT + b_kk) = vb;
+    };
+    f32x4 va = load_a(kbeg), vb = load_b(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage(va, vb);
         __syncthreads();
+        if (k0 + BK < kend) { va = load_a(k0 + BK); vb = load_b(k0 + BK); }     // in flight during the MFMAs
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + (wn + li) * LDT + 8 * h);
@@ -89,38 +116,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (m < M) C[(size_t)m * ldc + n] = acc[r] + bv;
+            if (m < M) {
+                if (gridDim.z > 1) atomicAdd(C + (size_t)m * ldc + n, acc[r]);
+                else C[(size_t)m * ldc + n] = acc[r] + bv;
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Column statistics of Z[M][H] (BatchNorm1d in train mode): mean, 1/sqrt(biased var + eps); updates
-// the running statistics (momentum 0.1, unbiased variance).  One block per 64 features, 256 threads
-// = 64 features x 4 row groups; two passes (mean, then centred squares).
-__global__ __launch_bounds__(256) void bn_stats_kernel(int M, int H, const float* __restrict__ Z, float* __restrict__ mu,
-                                                       float* __restrict__ inv, float* __restrict__ run_mean,
-                                                       float* __restrict__ run_var) {
-    __shared__ float red[4][64];
-    const int f = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const bool ok = f < H;
-    float s = 0.0f;
-    if (ok) for (int m = g; m < M; m += 4) s += Z[(size_t)m * H + f];
-    red[g][threadIdx.x & 63] = s;
-    __syncthreads();
-    const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)M;
-    __syncthreads();
-    float q = 0.0f;
-    if (ok) for (int m = g; m < M; m += 4) { const float d = Z[(size_t)m * H + f] - mean; q += d * d; }
-    red[g][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (g == 0 && ok) {
-        const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)M;
-        mu[f] = mean;
-        inv[f] = 1.0f / sqrtf(var + BN_EPS);
-        run_mean[f] = (1.0f - BN_MOMENTUM) * run_mean[f] + BN_MOMENTUM * mean;
-        run_var[f] = (1.0f - BN_MOMENTUM) * run_var[f] + BN_MOMENTUM * var * (float)M / (float)(M > 1 ? M - 1 : 1);
+// Column reductions over the batch.  A column sum over M rows with one block per 64 features would
+// leave 248 of 256 CUs idle (H = 512), so rows are split into RCHUNK chunks: partial kernels write
+// part[q][chunk][f] (deterministic, no atomics), finalize kernels add the chunks up per feature.
+constexpr int RCHUNK = 32;
+
+__device__ __forceinline__ void chunk_rows(int M, int& r0, int& r1) {
+    const int per = (M + RCHUNK - 1) / RCHUNK;
+    r0 = blockIdx.y * per;
+    r1 = r0 + per < M ? r0 + per : M;
+}
+
+// BatchNorm statistics, pass 1: sums of (z - pivot) and (z - pivot)^2 per feature and chunk, pivot = row 0
+// of the feature (a shift keeps E[d^2] - E[d]^2 well conditioned when |mean| >> std)
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(int M, int H, const float* __restrict__ Z,
+                                                               float* __restrict__ part) {
+    __shared__ float r1s[4][64], r2s[4][64];
+    const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
+    int r0, r1;
+    chunk_rows(M, r0, r1);
+    float s1 = 0.0f, s2 = 0.0f;
+    if (f < H) {
+        const float piv = Z[f];
+        for (int m = r0 + g; m < r1; m += 4) { const float d = Z[(size_t)m * H + f] - piv; s1 += d; s2 += d * d; }
     }
+    r1s[g][fl] = s1; r2s[g][fl] = s2;
+    __syncthreads();
+    if (g == 0 && f < H) {
+        part[((size_t)0 * RCHUNK + blockIdx.y) * H + f] = r1s[0][fl] + r1s[1][fl] + r1s[2][fl] + r1s[3][fl];
+        part[((size_t)1 * RCHUNK + blockIdx.y) * H + f] = r2s[0][fl] + r2s[1][fl] + r2s[2][fl] + r2s[3][fl];
+    }
+}
+// pass 2: mean, 1/sqrt(biased var + eps), running statistics (momentum 0.1, unbiased variance)
+__global__ void bn_stats_final_kernel(int M, int H, const float* __restrict__ Z, const float* __restrict__ part,
+                                      float* __restrict__ mu, float* __restrict__ inv, float* __restrict__ run_mean,
+                                      float* __restrict__ run_var) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= H) return;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = 0; c < RCHUNK; ++c) { s1 += part[((size_t)0 * RCHUNK + c) * H + f]; s2 += part[((size_t)1 * RCHUNK + c) * H + f]; }
+    const float dm = s1 / (float)M;
+    const float mean = Z[f] + dm;
+    float var = s2 / (float)M - dm * dm;
+    var = var > 0.0f ? var : 0.0f;
+    mu[f] = mean;
+    inv[f] = 1.0f / sqrtf(var + BN_EPS);
+    run_mean[f] = (1.0f - BN_MOMENTUM) * run_mean[f] + BN_MOMENTUM * mean;
+    run_var[f] = (1.0f - BN_MOMENTUM) * run_var[f] + BN_MOMENTUM * var * (float)M / (float)(M > 1 ? M - 1 : 1);
 }
 
 // out = relu(bn(z)) element-wise; mu/inv are the batch statistics (train) or derived from the running
@@ -154,19 +205,21 @@ __global__ void l1_kernel(size_t n, const float* __restrict__ P, const float* __
     if (loss && (threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(loss, a);
 }
 
-// Backward through ReLU and BatchNorm, pass 1: D <- D * (y > 0) in place; per feature
-// dbeta = sum D, dgamma = sum D * xhat  (without BatchNorm: dbeta only = the bias gradient).
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int H, float* __restrict__ D, const float* __restrict__ Z,
-                                                            const float* __restrict__ mu, const float* __restrict__ inv,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// Backward through ReLU and BatchNorm, pass 1: D <- D * (y > 0) in place; per feature and row chunk
+// the partial sums of D (-> dbeta, or the bias gradient without BatchNorm) and of D * xhat (-> dgamma)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int M, int H, float* __restrict__ D, const float* __restrict__ Z,
+                                                             const float* __restrict__ mu, const float* __restrict__ inv,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ part) {
     __shared__ float rb[4][64], rg[4][64];
     const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
+    int r0, r1;
+    chunk_rows(M, r0, r1);
     float sb = 0.0f, sg = 0.0f;
     if (f < H) {
         const bool bn = mu != nullptr;
         const float m_ = bn ? mu[f] : 0.0f, iv = bn ? inv[f] : 1.0f, ga = bn ? gamma[f] : 1.0f, be = bn ? beta[f] : 0.0f;
-        for (int m = g; m < M; m += 4) {
+        for (int m = r0 + g; m < r1; m += 4) {
             const size_t i = (size_t)m * H + f;
             const float xhat = (Z[i] - m_) * iv;
             const float y = bn ? xhat * ga + be : Z[i];
@@ -178,9 +231,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int H, float*
     rb[g][fl] = sb; rg[g][fl] = sg;
     __syncthreads();
     if (g == 0 && f < H) {
-        dbeta[f] = rb[0][fl] + rb[1][fl] + rb[2][fl] + rb[3][fl];
-        if (dgamma) dgamma[f] = rg[0][fl] + rg[1][fl] + rg[2][fl] + rg[3][fl];
+        part[((size_t)0 * RCHUNK + blockIdx.y) * H + f] = rb[0][fl] + rb[1][fl] + rb[2][fl] + rb[3][fl];
+        part[((size_t)1 * RCHUNK + blockIdx.y) * H + f] = rg[0][fl] + rg[1][fl] + rg[2][fl] + rg[3][fl];
     }
+}
+// column sums of D[M][H], partial
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int M, int H, const float* __restrict__ D, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
+    int r0, r1;
+    chunk_rows(M, r0, r1);
+    float s = 0.0f;
+    if (f < H) for (int m = r0 + g; m < r1; m += 4) s += D[(size_t)m * H + f];
+    red[g][fl] = s;
+    __syncthreads();
+    if (g == 0 && f < H) part[(size_t)blockIdx.y * H + f] = red[0][fl] + red[1][fl] + red[2][fl] + red[3][fl];
+}
+// out0[f] = sum of part[0][.][f], out1[f] = sum of part[1][.][f] (out1 may be null)
+__global__ void reduce_final_kernel(int H, const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= H) return;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int c = 0; c < RCHUNK; ++c) {
+        s0 += part[((size_t)0 * RCHUNK + c) * H + f];
+        if (out1) s1 += part[((size_t)1 * RCHUNK + c) * H + f];
+    }
+    out0[f] = s0;
+    if (out1) out1[f] = s1;
 }
 
 // pass 2 (BatchNorm only): dz = gamma inv / M (M d - dbeta - xhat dgamma), in place
@@ -193,17 +270,6 @@ __global__ void bn_bwd_apply_kernel(size_t n, int M, int H, float* __restrict__ 
     const int f = (int)(i % H);
     const float xhat = (Z[i] - mu[f]) * inv[f];
     D[i] = gamma[f] * inv[f] / (float)M * ((float)M * D[i] - dbeta[f] - xhat * dgamma[f]);
-}
-
-// column sums of D[M][H] (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int H, const float* __restrict__ D, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (f < H) for (int m = g; m < M; m += 4) s += D[(size_t)m * H + f];
-    red[g][fl] = s;
-    __syncthreads();
-    if (g == 0 && f < H) out[f] = red[0][fl] + red[1][fl] + red[2][fl] + red[3][fl];
 }
 
 // torch.optim.Adam, defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay); c1 = 1 - b1^t, c2 = 1 - b2^t
@@ -239,6 +305,7 @@ struct Policy {
     float *z = nullptr;        // pre-BatchNorm outputs z_l  [L][B][hidden]
     float *dbuf[2] = {nullptr, nullptr};   // [B][max(hidden, n_in)]
     float *pred = nullptr, *dpred = nullptr;
+    float *part = nullptr;     // partial column sums [2][RCHUNK][max(hidden, n_out)]
     long long step = 0;
     std::string err;
 };
@@ -253,14 +320,26 @@ int pfail(Policy* p, int code, const std::string& msg) {
         if (e_ != hipSuccess) return pfail(p, NMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// split_k > 1: C must be zero on entry (partial products are added with atomics); no bias then
 template <bool TA, bool TB>
 void gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias) {
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
+          const float* bias, int split_k = 1) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    const bool vec = aligned && M % BM == 0 && N % BN == 0 && K % (BK * split_k) == 0 && lda % 4 == 0 && ldb % 4 == 0;
+    if (!vec) split_k = 1;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    if (vec) hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
+    else hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
 }
 
+constexpr int SPLIT_K = 4;    // of the weight-gradient GEMMs (contraction over the batch, 64 output tiles at hidden = 512)
+
 unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+void colsum(Policy* p, hipStream_t st, int M, int H, const float* D, float* out) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, M, H, D, p->part);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, p->part, out, (float*)nullptr);
+}
 
 // forward pass; train: batch statistics (and the caches z, act for the backward pass)
 int forward(Policy* p, int B, const float* X, float* out, bool train, hipStream_t st) {
@@ -275,7 +354,8 @@ int forward(Policy* p, int B, const float* X, float* out, bool train, hipStream_
         if (p->d.batch_norm) {
             float *mu = p->mu + (size_t)l * H, *inv = p->inv + (size_t)l * H;
             if (train) {
-                hipLaunchKernelGGL(bn_stats_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, z, mu, inv,
+                hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, z, p->part);
+                hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, B, H, z, p->part, mu, inv,
                                    p->run_mean + (size_t)l * H, p->run_var + (size_t)l * H);
                 hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, H, z, mu, inv, false,
                                    p->theta + p->og[l], p->theta + p->obe[l], o);
@@ -324,7 +404,8 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->theta, off}, {&p->grad, off}, {&p->m, off}, {&p->v, off},
         {&p->run_mean, (size_t)L * H}, {&p->run_var, (size_t)L * H}, {&p->mu, (size_t)L * H}, {&p->inv, (size_t)L * H},
         {&p->act, (size_t)L * Bm * H}, {&p->z, (size_t)L * Bm * H}, {&p->dbuf[0], Bm * wide}, {&p->dbuf[1], Bm * wide},
-        {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out}};
+        {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out},
+        {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)}};
     hipError_t e = hipSetDevice(device_id);
     for (auto& b : bufs) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b.ptr), b.n * sizeof(float));
@@ -345,7 +426,7 @@ void nmpc_policy_destroy(void* handle) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
-                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred};
+                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part};
     for (float* q : all) if (q) (void)hipFree(q);
     delete p;
 }
@@ -418,6 +499,7 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     PTRY(p, hipSetDevice(p->device));
     const int L = p->d.n_hidden, H = p->d.hidden, no = p->d.n_out;
     const bool bn = p->d.batch_norm != 0;
+    PTRY(p, hipMemsetAsync(p->grad, 0, p->n_theta * sizeof(float), st));     // split-K GEMMs accumulate into it
     forward(p, B, X, p->pred, true, st);
     if (pred) PTRY(p, hipMemcpyAsync(pred, p->pred, (size_t)B * no * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (loss) PTRY(p, hipMemsetAsync(loss, 0, sizeof(float), st));
@@ -425,8 +507,8 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, p->pred, Y, p->dpred, loss);
     // output layer: dW = dP' a_L, db = colsum dP, d = dP W
     const float* aL = p->act + (size_t)(L - 1) * p->d.batch_max * H;
-    gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr);
-    hipLaunchKernelGGL(colsum_kernel, dim3((no + 63) / 64), dim3(256), 0, st, B, no, p->dpred, p->grad + p->ob[L]);
+    gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr, SPLIT_K);
+    colsum(p, st, B, no, p->dpred, p->grad + p->ob[L]);
     float* d = p->dbuf[0];
     float* dn = p->dbuf[1];
     gemm<false, true>(st, B, H, no, p->dpred, no, p->theta + p->oW[L], H, d, H, nullptr);
@@ -437,15 +519,16 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
         const float *mu = bn ? p->mu + (size_t)l * H : nullptr, *inv = bn ? p->inv + (size_t)l * H : nullptr;
         float* dgamma = bn ? p->grad + p->og[l] : nullptr;
         float* dbeta = bn ? p->grad + p->obe[l] : p->grad + p->ob[l];
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, d, z, mu, inv,
-                           bn ? p->theta + p->og[l] : nullptr, bn ? p->theta + p->obe[l] : nullptr, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, d, z, mu, inv,
+                           bn ? p->theta + p->og[l] : nullptr, bn ? p->theta + p->obe[l] : nullptr, p->part);
+        hipLaunchKernelGGL(reduce_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, p->part, dbeta, dgamma);
         if (bn) {
             const size_t n = (size_t)B * H;
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, B, H, d, z, mu, inv,
                                p->theta + p->og[l], dgamma, dbeta);
-            hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64), dim3(256), 0, st, B, H, d, p->grad + p->ob[l]);
+            colsum(p, st, B, H, d, p->grad + p->ob[l]);
         }
-        gemm<true, true>(st, H, fan_in, B, d, H, a, fan_in, p->grad + p->oW[l], fan_in, nullptr);
+        gemm<true, true>(st, H, fan_in, B, d, H, a, fan_in, p->grad + p->oW[l], fan_in, nullptr, SPLIT_K);
         if (l > 0) {
             gemm<false, true>(st, B, H, H, d, H, p->theta + p->oW[l], H, dn, H, nullptr);
             float* t = d; d = dn; dn = t;
