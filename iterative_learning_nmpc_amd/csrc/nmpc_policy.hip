@@ -34,11 +34,11 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 // 32w + i and the k slots 8h .. 8h+7 of the slice as two 16 B reads per operand (the order of the
 // k terms is irrelevant as long as A and B agree), eight MFMAs per slice.
 // VEC = false: loads are guarded element-wise (K = 47, N = 12 ... are not tile multiples; rows of X
-// are not 16 B aligned).  VEC = true (M, N multiples of 64, K of 16 x gridDim.z, leading dimensions
-// multiples of 4): 16 B global loads without guards, the next K slice prefetched into registers while
-// the current one is multiplied.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
-// batch and have only 64 output tiles): the partial products are added to C with float atomics, C
-// zeroed by the caller.
+// are not 16 B aligned).  VEC = true (M, N multiples of 64, K of 16, leading dimensions multiples of
+// 4): 16 B global loads without guards.  The next K slice is prefetched into registers while the
+// current one is multiplied.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
+// batch and have few output tiles: 64 at hidden = 512, 8 for the input and output layers): the
+// partial products are added to C with float atomics, C zeroed by the caller.
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
 
 template <bool TA, bool TB, bool VEC>
@@ -51,8 +51,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = 32 * (w >> 1), wn = 32 * (w & 1);
     const int h = lane >> 5, li = lane & 31;
-    const int kper = K / (int)gridDim.z;                          // gridDim.z > 1 only with VEC
-    const int kbeg = blockIdx.z * kper, kend = (gridDim.z > 1) ? kbeg + kper : K;
+    // K range of this block: whole slices of BK per split (the last split may be short or empty)
+    const int kper = (((K + (int)gridDim.z - 1) / (int)gridDim.z) + BK - 1) / BK * BK;
+    const int kbeg = blockIdx.z * kper, kend = kbeg + kper < K ? kbeg + kper : K;
+    if (kbeg >= kend) return;                                     // an empty split (block-uniform)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -325,9 +327,10 @@ template <bool TA, bool TB>
 void gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
           const float* bias, int split_k = 1) {
     const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
-    const bool vec = aligned && M % BM == 0 && N % BN == 0 && K % (BK * split_k) == 0 && lda % 4 == 0 && ldb % 4 == 0;
-    if (!vec) split_k = 1;
+    const bool vec = aligned && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    // more splits for GEMMs with very few output tiles
+    while (split_k > 1 && grid.x * grid.y * grid.z < 128 && (int)grid.z * 2 * BK <= K) grid.z *= 2;
     if (vec) hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
     else hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
 }
