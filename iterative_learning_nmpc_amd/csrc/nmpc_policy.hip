@@ -158,22 +158,43 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(int M, int H, con
         part[((size_t)1 * RCHUNK + blockIdx.y) * H + f] = r2s[0][fl] + r2s[1][fl] + r2s[2][fl] + r2s[3][fl];
     }
 }
-// pass 2: mean, 1/sqrt(biased var + eps), running statistics (momentum 0.1, unbiased variance)
-__global__ void bn_stats_final_kernel(int M, int H, const float* __restrict__ Z, const float* __restrict__ part,
-                                      float* __restrict__ mu, float* __restrict__ inv, float* __restrict__ run_mean,
-                                      float* __restrict__ run_var) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+
+// Train-mode BatchNorm + ReLU with the statistics finalised in the same launch: a block owns 64
+// features x one row chunk, adds up the RCHUNK partial sums of its features (pass 1 above), and
+// applies them to its rows; the blocks of chunk 0 also publish mean, 1/sqrt(var + eps) for the
+// backward pass and update the running statistics (momentum 0.1, unbiased variance).
+__global__ __launch_bounds__(256) void bn_relu_train_kernel(int M, int H, const float* __restrict__ Z,
+                                                            const float* __restrict__ part, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out,
+                                                            float* __restrict__ mu, float* __restrict__ inv,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var) {
+    __shared__ float smu[64], sinv[64];
+    const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
+    if (g == 0 && f < H) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int c = 0; c < RCHUNK; ++c) { s1 += part[((size_t)0 * RCHUNK + c) * H + f]; s2 += part[((size_t)1 * RCHUNK + c) * H + f]; }
+        const float dm = s1 / (float)M;
+        const float mean = Z[f] + dm;
+        float var = s2 / (float)M - dm * dm;
+        var = var > 0.0f ? var : 0.0f;
+        const float iv = 1.0f / sqrtf(var + BN_EPS);
+        smu[fl] = mean; sinv[fl] = iv;
+        if (blockIdx.y == 0) {
+            mu[f] = mean; inv[f] = iv;
+            run_mean[f] = (1.0f - BN_MOMENTUM) * run_mean[f] + BN_MOMENTUM * mean;
+            run_var[f] = (1.0f - BN_MOMENTUM) * run_var[f] + BN_MOMENTUM * var * (float)M / (float)(M > 1 ? M - 1 : 1);
+        }
+    }
+    __syncthreads();
     if (f >= H) return;
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int c = 0; c < RCHUNK; ++c) { s1 += part[((size_t)0 * RCHUNK + c) * H + f]; s2 += part[((size_t)1 * RCHUNK + c) * H + f]; }
-    const float dm = s1 / (float)M;
-    const float mean = Z[f] + dm;
-    float var = s2 / (float)M - dm * dm;
-    var = var > 0.0f ? var : 0.0f;
-    mu[f] = mean;
-    inv[f] = 1.0f / sqrtf(var + BN_EPS);
-    run_mean[f] = (1.0f - BN_MOMENTUM) * run_mean[f] + BN_MOMENTUM * mean;
-    run_var[f] = (1.0f - BN_MOMENTUM) * run_var[f] + BN_MOMENTUM * var * (float)M / (float)(M > 1 ? M - 1 : 1);
+    int r0, r1;
+    chunk_rows(M, r0, r1);
+    const float m_ = smu[fl], iv = sinv[fl], ga = gamma[f], be = beta[f];
+    for (int m = r0 + g; m < r1; m += 4) {
+        const size_t i = (size_t)m * H + f;
+        const float y = (Z[i] - m_) * iv * ga + be;
+        out[i] = y > 0.0f ? y : 0.0f;
+    }
 }
 
 // out = relu(bn(z)) element-wise; mu/inv are the batch statistics (train) or derived from the running
@@ -262,16 +283,50 @@ __global__ void reduce_final_kernel(int H, const float* __restrict__ part, float
     if (out1) out1[f] = s1;
 }
 
-// pass 2 (BatchNorm only): dz = gamma inv / M (M d - dbeta - xhat dgamma), in place
-__global__ void bn_bwd_apply_kernel(size_t n, int M, int H, float* __restrict__ D, const float* __restrict__ Z,
-                                    const float* __restrict__ mu, const float* __restrict__ inv,
-                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int f = (int)(i % H);
-    const float xhat = (Z[i] - mu[f]) * inv[f];
-    D[i] = gamma[f] * inv[f] / (float)M * ((float)M * D[i] - dbeta[f] - xhat * dgamma[f]);
+// pass 2 (BatchNorm only), same block shape as pass 1: adds up the partial sums (-> dgamma, dbeta,
+// published by the blocks of chunk 0), applies  dz = gamma inv / M (M d - dbeta - xhat dgamma)  in
+// place to its rows, and leaves the partial column sums of dz (the bias gradient in front of the
+// BatchNorm -- zero up to rounding, but the reference's Adam steps on it) in part_b[chunk][f].
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int H, float* __restrict__ D, const float* __restrict__ Z,
+                                                           const float* __restrict__ mu, const float* __restrict__ inv,
+                                                           const float* __restrict__ gamma, const float* __restrict__ part,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ part_b) {
+    __shared__ float sdg[64], sdb[64], red[4][64];
+    const int fl = threadIdx.x & 63, f = blockIdx.x * 64 + fl, g = threadIdx.x >> 6;
+    if (g == 0 && f < H) {
+        float s0 = 0.0f, s1 = 0.0f;
+        for (int c = 0; c < RCHUNK; ++c) { s0 += part[((size_t)0 * RCHUNK + c) * H + f]; s1 += part[((size_t)1 * RCHUNK + c) * H + f]; }
+        sdb[fl] = s0; sdg[fl] = s1;
+        if (blockIdx.y == 0) { dbeta[f] = s0; dgamma[f] = s1; }
+    }
+    __syncthreads();
+    int r0, r1;
+    chunk_rows(M, r0, r1);
+    float sb = 0.0f;
+    if (f < H) {
+        const float m_ = mu[f], iv = inv[f], c = gamma[f] * iv / (float)M, db = sdb[fl], dg = sdg[fl];
+        for (int m = r0 + g; m < r1; m += 4) {
+            const size_t i = (size_t)m * H + f;
+            const float xhat = (Z[i] - m_) * iv;
+            const float dz = c * ((float)M * D[i] - db - xhat * dg);
+            D[i] = dz;
+            sb += dz;
+        }
+    }
+    red[g][fl] = sb;
+    __syncthreads();
+    if (g == 0 && f < H) part_b[(size_t)blockIdx.y * H + f] = red[0][fl] + red[1][fl] + red[2][fl] + red[3][fl];
+}
+
+// bias gradients of all hidden layers from their partial sums: grad[ob[l] + f] = sum_c part_b[l][c][f]
+__global__ void bias_grad_final_kernel(int H, const float* __restrict__ part_b, float* __restrict__ grad,
+                                       const unsigned long long* __restrict__ ob) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (f >= H) return;
+    float s = 0.0f;
+    for (int c = 0; c < RCHUNK; ++c) s += part_b[((size_t)l * RCHUNK + c) * H + f];
+    grad[ob[l] + f] = s;
 }
 
 // torch.optim.Adam, defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay); c1 = 1 - b1^t, c2 = 1 - b2^t
@@ -308,6 +363,8 @@ struct Policy {
     float *dbuf[2] = {nullptr, nullptr};   // [B][max(hidden, n_in)]
     float *pred = nullptr, *dpred = nullptr;
     float *part = nullptr;     // partial column sums [2][RCHUNK][max(hidden, n_out)]
+    float *part_b = nullptr;   // partial bias-gradient sums of the hidden layers [L][RCHUNK][hidden]
+    unsigned long long* ob_dev = nullptr;   // ob[] on the device
     long long step = 0;
     std::string err;
 };
@@ -358,10 +415,9 @@ int forward(Policy* p, int B, const float* X, float* out, bool train, hipStream_
             float *mu = p->mu + (size_t)l * H, *inv = p->inv + (size_t)l * H;
             if (train) {
                 hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, z, p->part);
-                hipLaunchKernelGGL(bn_stats_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, B, H, z, p->part, mu, inv,
+                hipLaunchKernelGGL(bn_relu_train_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, z, p->part,
+                                   p->theta + p->og[l], p->theta + p->obe[l], o, mu, inv,
                                    p->run_mean + (size_t)l * H, p->run_var + (size_t)l * H);
-                hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, H, z, mu, inv, false,
-                                   p->theta + p->og[l], p->theta + p->obe[l], o);
             } else {
                 hipLaunchKernelGGL(bn_relu_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, H, z,
                                    p->run_mean + (size_t)l * H, p->run_var + (size_t)l * H, true,
@@ -408,7 +464,8 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->run_mean, (size_t)L * H}, {&p->run_var, (size_t)L * H}, {&p->mu, (size_t)L * H}, {&p->inv, (size_t)L * H},
         {&p->act, (size_t)L * Bm * H}, {&p->z, (size_t)L * Bm * H}, {&p->dbuf[0], Bm * wide}, {&p->dbuf[1], Bm * wide},
         {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out},
-        {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)}};
+        {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)},
+        {&p->part_b, (size_t)L * RCHUNK * H}};
     hipError_t e = hipSetDevice(device_id);
     for (auto& b : bufs) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b.ptr), b.n * sizeof(float));
@@ -420,6 +477,17 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         delete p;
         return NMPC_E_HIP;
     }
+    {   // bias offsets of the hidden layers for bias_grad_final_kernel
+        unsigned long long ob[16];
+        for (int l = 0; l < L; ++l) ob[l] = p->ob[l];
+        e = hipMalloc(reinterpret_cast<void**>(&p->ob_dev), sizeof(ob));
+        if (e == hipSuccess) e = hipMemcpy(p->ob_dev, ob, sizeof(ob), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            g_policy_create_error = std::string("nmpc_policy_create: ") + hipGetErrorString(e);
+            nmpc_policy_destroy(p);
+            return NMPC_E_HIP;
+        }
+    }
     *handle = p;
     return NMPC_OK;
 }
@@ -429,8 +497,9 @@ void nmpc_policy_destroy(void* handle) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
-                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part};
+                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b};
     for (float* q : all) if (q) (void)hipFree(q);
+    if (p->ob_dev) (void)hipFree(p->ob_dev);
     delete p;
 }
 
@@ -524,12 +593,11 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
         float* dbeta = bn ? p->grad + p->obe[l] : p->grad + p->ob[l];
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, d, z, mu, inv,
                            bn ? p->theta + p->og[l] : nullptr, bn ? p->theta + p->obe[l] : nullptr, p->part);
-        hipLaunchKernelGGL(reduce_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, p->part, dbeta, dgamma);
         if (bn) {
-            const size_t n = (size_t)B * H;
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, B, H, d, z, mu, inv,
-                               p->theta + p->og[l], dgamma, dbeta);
-            colsum(p, st, B, H, d, p->grad + p->ob[l]);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((H + 63) / 64, RCHUNK), dim3(256), 0, st, B, H, d, z, mu, inv,
+                               p->theta + p->og[l], p->part, dgamma, dbeta, p->part_b + (size_t)l * RCHUNK * H);
+        } else {
+            hipLaunchKernelGGL(reduce_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, p->part, dbeta, (float*)nullptr);
         }
         gemm<true, true>(st, H, fan_in, B, d, H, a, fan_in, p->grad + p->oW[l], fan_in, nullptr, SPLIT_K);
         if (l > 0) {
@@ -537,6 +605,9 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
             float* t = d; d = dn; dn = t;
         }
     }
+    if (bn)
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((H + 255) / 256, L), dim3(256), 0, st, H, p->part_b, p->grad,
+                           p->ob_dev);
     p->step += 1;
     const float c1 = 1.0f - std::pow(ADAM_B1, (float)p->step), c2 = 1.0f - std::pow(ADAM_B2, (float)p->step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(p->n_theta)), dim3(256), 0, st, p->n_theta, p->theta, p->grad,
