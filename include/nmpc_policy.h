@@ -54,6 +54,18 @@ int nmpc_policy_forward(void *handle, int B, const float *X, float *Y, void *str
 int nmpc_policy_train_step(void *handle, int B, const float *X, const float *Y, float lr, float *loss,
                            float *pred, void *stream);
 
+/* torch.utils.data.WeightedRandomSampler(weights, num_samples, replacement=True)
+ * (Behavior_Cloning/examples/test_train_policy.py:128-134) on device weights -- e.g. the OOD weights
+ * nmpc_tracking_error wrote:  idx[i] ~ weights / sum(weights),  0 <= i < num_samples.  Sample i is the
+ * inverse-CDF lookup of a uniform number made by the counter-based Philox-4x32-10 generator from
+ * (seed, i): reproducible for a seed whatever the launch shape, and restated bit for bit by the oracle.
+ * scratch: n + n/2048 + 2 doubles of device memory.  Stateless (no handle). */
+int nmpc_weighted_sample(const float *weights, long long n, int num_samples, unsigned long long seed,
+                         double *scratch, int *idx, void *stream);
+
+/* Batch assembly behind the sampler: dst[i][0..row_len) = src[idx[i]][0..row_len). */
+int nmpc_gather_rows(const float *src, int row_len, const int *idx, int n_idx, float *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nmpc_policy_get_params": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nmpc_policy_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_policy_train_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "nmpc_weighted_sample": (c_int, [c_void_p, ctypes.c_longlong, c_int, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p]),
+    "nmpc_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }

@@ -341,6 +341,83 @@ __global__ void adam_kernel(size_t n, float* __restrict__ theta, const float* __
     theta[i] -= lr * (mi / c1) / (sqrtf(vi / c2) + ADAM_EPS);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weighted sampling with replacement: fp64 inclusive prefix sums of the weights (blocks of SCAN_CHUNK
+// elements: local sums -> scan of the block totals -> local scan with offset), then one inverse-CDF
+// lookup per sample with a Philox-4x32-10 uniform number.
+constexpr int SCAN_CHUNK = 2048;   // 256 threads x 8
+
+__global__ __launch_bounds__(256) void scan_block_totals_kernel(const float* __restrict__ w, long long n, double* __restrict__ tot) {
+    __shared__ double red[256];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK;
+    double s = 0.0;
+    for (int e = 0; e < 8; ++e) {
+        const long long i = base + (long long)threadIdx.x * 8 + e;
+        if (i < n) s += (double)w[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) tot[blockIdx.x] = red[0];
+}
+// exclusive scan of the block totals in place, total weight to tot[nb] (one thread: nb is n / 2048)
+__global__ void scan_totals_kernel(double* __restrict__ tot, long long nb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double run = 0.0;
+    for (long long b = 0; b < nb; ++b) { const double t = tot[b]; tot[b] = run; run += t; }
+    tot[nb] = run;
+}
+__global__ __launch_bounds__(256) void scan_write_kernel(const float* __restrict__ w, long long n, const double* __restrict__ tot,
+                                                         double* __restrict__ cdf) {
+    __shared__ double pre[256];
+    const long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * 8;
+    double v[8], s = 0.0;
+    for (int e = 0; e < 8; ++e) { v[e] = (base + e < n) ? (double)w[base + e] : 0.0; s += v[e]; }
+    pre[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double run = 0.0; for (int t = 0; t < 256; ++t) { const double x = pre[t]; pre[t] = run; run += x; } }
+    __syncthreads();
+    double run = tot[blockIdx.x] + pre[threadIdx.x];
+    for (int e = 0; e < 8; ++e) { run += v[e]; if (base + e < n) cdf[base + e] = run; }
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned& o0, unsigned& o1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1;
+}
+
+// (the total weight is read from the device: no host round trip)
+__global__ void sample_kernel(const double* __restrict__ cdf, long long n, const double* __restrict__ total_ptr,
+                                          int num_samples, unsigned long long seed, int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_samples) return;
+    unsigned a, b;
+    philox4x32_10((unsigned)i, 0u, 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), a, b);
+    const double u = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);   // 53 bits in [0, 1)
+    const double target = u * total_ptr[0];
+    long long lo = 0, hi = n - 1;                      // first index with cdf > target
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (cdf[mid] > target) hi = mid; else lo = mid + 1;
+    }
+    idx[i] = (int)lo;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int row_len, const int* __restrict__ idx, int n_idx,
+                                   float* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n_idx * row_len) return;
+    const int i = (int)(e / row_len), j = (int)(e - (size_t)i * row_len);
+    dst[e] = src[(size_t)idx[i] * row_len + j];
+}
+
 }  // namespace nmpc_policy
 
 // ================================================================================================
@@ -613,6 +690,37 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(p->n_theta)), dim3(256), 0, st, p->n_theta, p->theta, p->grad,
                        p->m, p->v, lr, c1, c2);
     PTRY(p, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_weighted_sample(const float* weights, long long n, int num_samples, unsigned long long seed, double* scratch,
+                         int* idx, void* stream) {
+    if (num_samples == 0) return NMPC_OK;
+    if (!weights || !scratch || !idx) return pfail(nullptr, NMPC_E_ARG, "null argument");
+    if (n < 1 || n > 0x7fffffffLL || num_samples < 0) return pfail(nullptr, NMPC_E_ARG, "need 1 <= n < 2^31, num_samples >= 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    double* cdf = scratch;
+    double* tot = scratch + n;                        // nb + 1 doubles
+    hipLaunchKernelGGL(scan_block_totals_kernel, dim3((unsigned)nb), dim3(256), 0, st, weights, n, tot);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(64), 0, st, tot, nb);
+    hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, weights, n, tot, cdf);
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((num_samples + 255) / 256)), dim3(256), 0, st, cdf, n, tot + nb,
+                       num_samples, seed, idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pfail(nullptr, NMPC_E_HIP, hipGetErrorString(e));
+    return NMPC_OK;
+}
+
+int nmpc_gather_rows(const float* src, int row_len, const int* idx, int n_idx, float* dst, void* stream) {
+    if (n_idx == 0) return NMPC_OK;
+    if (!src || !idx || !dst) return pfail(nullptr, NMPC_E_ARG, "null argument");
+    if (row_len < 1 || n_idx < 0) return pfail(nullptr, NMPC_E_ARG, "need row_len >= 1, n_idx >= 0");
+    const size_t n = (size_t)n_idx * row_len;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, row_len, idx, n_idx, dst);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pfail(nullptr, NMPC_E_HIP, hipGetErrorString(e));
     return NMPC_OK;
 }
 

@@ -146,3 +146,30 @@ class DevicePolicy:
         self._check(self.lib.nmpc_policy_train_step(self._h, B, _ptr(x), _ptr(y), float(lr), _ptr(loss), _ptr(pred),
                                                     _stream(self.device)), "nmpc_policy_train_step")
         return (loss, pred) if return_pred else loss
+
+
+def weighted_sample(weights: torch.Tensor, num_samples: int, seed: int) -> torch.Tensor:
+    """WeightedRandomSampler(weights, num_samples, replacement=True) on device weights
+    (test_train_policy.py:128-134): int32 indices [num_samples], reproducible for a seed."""
+    lib = _lib.load()
+    w = weights.reshape(-1)
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    n = w.numel()
+    scratch = torch.empty(n + n // 2048 + 2, dtype=torch.float64, device=w.device)
+    idx = torch.empty(num_samples, dtype=torch.int32, device=w.device)
+    rc = lib.nmpc_weighted_sample(_ptr(w), n, int(num_samples), int(seed) & (2 ** 64 - 1), _ptr(scratch), _ptr(idx), _stream(w.device))
+    if rc:
+        raise _lib.NmpcError(f"nmpc_weighted_sample: {lib.nmpc_policy_last_error(None).decode()}")
+    return idx
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Batch assembly behind the sampler: src[idx] for a [rows, features] fp32 table."""
+    lib = _lib.load()
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 2
+    assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
+    dst = torch.empty(idx.numel(), src.shape[1], dtype=torch.float32, device=src.device)
+    rc = lib.nmpc_gather_rows(_ptr(src), src.shape[1], _ptr(idx), idx.numel(), _ptr(dst), _stream(src.device))
+    if rc:
+        raise _lib.NmpcError(f"nmpc_gather_rows: {lib.nmpc_policy_last_error(None).decode()}")
+    return dst

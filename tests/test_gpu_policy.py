@@ -113,3 +113,43 @@ def test_policy_argument_errors():
         pol.train_step(x[:1].contiguous(), y[:1].contiguous())          # BatchNorm needs two rows
     with pytest.raises(_lib.NmpcError):
         pol.train_step(x[:4].contiguous(), y[:4].contiguous(), lr=0.0)
+
+
+@pytest.mark.parametrize("n,num", [(1000, 4096), (5000, 100), (2048 * 3 + 17, 9000), (1, 7)])
+def test_weighted_sampler_is_bit_exact(n, num):
+    """Index work: the device sampler equals the oracle's restatement (same Philox numbers, same
+    inverse-CDF lookup) for the reference's weights (1 or 5: the fp64 prefix sums are exact)."""
+    from iterative_learning_nmpc_amd.policy import weighted_sample
+    from oracle.policy_oracle import weighted_sample as oracle_sample
+    rng = np.random.default_rng(n)
+    w = np.where(rng.random(n) < 0.15, 5.0, 1.0).astype(np.float32)
+    idx = weighted_sample(torch.tensor(w, device="cuda:0"), num, seed=1234567891011).cpu().numpy()
+    assert np.array_equal(idx, oracle_sample(w, num, 1234567891011))
+
+
+def test_weighted_sampler_follows_tracking_error_weights_and_gathers_batches():
+    """nmpc_tracking_error's OOD weights -> sampler -> batch of rows (the reference's data loader,
+    test_train_policy.py:128-134): frequencies follow the weights, the gathered rows are the table's."""
+    from iterative_learning_nmpc_amd.policy import gather_rows, weighted_sample
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    B, T, ns = 40, 50, 19
+    S = torch.tensor(rng.normal(0, 1.0, (B, T, ns)), dtype=torch.float32, device=dev)
+    err, wgt = tracking_error(S, S[0].contiguous(), threshold=6.0, ood_weight=5.0)
+    w = wgt.reshape(-1)
+    ood = (w > 1.0)
+    assert 0.02 < ood.float().mean().item() < 0.98
+    idx = weighted_sample(w, 400000, seed=5)
+    hit = ood[idx.long()].float().mean().item()
+    expect = (5.0 * ood.sum() / (5.0 * ood.sum() + (~ood).sum())).item()
+    assert abs(hit - expect) < 0.005
+    table = S.reshape(B * T, ns).contiguous()
+    batch = gather_rows(table, idx[:1024].contiguous())
+    assert torch.equal(batch, table[idx[:1024].long()])
+    # arbitrary positive weights: statistical agreement (prefix sums differ in the last bits)
+    w2 = torch.tensor(rng.random(3000).astype(np.float32) + 0.01, device=dev)
+    i2 = weighted_sample(w2, 600000, seed=9).cpu().numpy()
+    freq = np.bincount(i2, minlength=3000) / 600000.0
+    p = (w2 / w2.sum()).cpu().numpy()
+    assert np.abs(freq - p).max() < 5 * np.sqrt(p.max() / 600000.0)

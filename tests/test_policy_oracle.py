@@ -43,3 +43,17 @@ def test_policy_oracle_matches_reference_network(name):
         assert np.abs(o.running_var - ref_final.running_var).max() < 1e-6
     # eval-mode forward (running statistics) on the reference's own final parameters
     assert np.abs(ref_final.forward(g["X"][0], train=False) - g["eval_pred"]).max() < 2e-5
+
+
+def test_philox_known_answer_and_sampler_distribution():
+    """Philox-4x32-10 against the Random123 known-answer vector (counter 0, key 0), and the sampler's
+    frequencies against the weights."""
+    from oracle.policy_oracle import philox4x32_10, weighted_sample
+    a, b = philox4x32_10(np.array([0]), 0)
+    assert (int(a[0]), int(b[0])) == (0x6627E8D5, 0xE169C58D)
+    w = np.ones(1000); w[::10] = 5.0                                # WeightedRandomSampler weights of test_train_policy.py:128-132
+    idx = weighted_sample(w, 200000, seed=3)
+    assert idx.min() >= 0 and idx.max() < 1000
+    share = np.isin(idx, np.arange(0, 1000, 10)).mean()
+    assert abs(share - 500.0 / 1400.0) < 0.005                       # 100 x 5 / (900 + 500)
+    assert np.array_equal(idx, weighted_sample(w, 200000, seed=3)) and not np.array_equal(idx, weighted_sample(w, 200000, seed=4))
