@@ -45,8 +45,8 @@ template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                    int ldc, const float* __restrict__ bias) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    __shared__ __attribute__((aligned(16))) float As2[2][BM * LDT];    // double-buffered: one barrier per slice
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = 32 * (w >> 1), wn = 32 * (w & 1);
@@ -90,17 +90,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         }
         return v;
     };
-    auto stage = [&](f32x4 va, f32x4 vb) {
+    auto stage = [&](int buf, f32x4 va, f32x4 vb) {
+        float* As = As2[buf];
+        float* Bs = Bs2[buf];
         if (TA) { for (int e = 0; e < 4; ++e) As[(a_row + e) * LDT + a_kk] = va[e]; }
         else *reinterpret_cast<f32x4*>(As + a_row * LDT + a_kk) = va;
         if (TB) { for (int e = 0; e < 4; ++e) Bs[(b_row + e) * LDT + b_kk] = vb[e]; }
         else *reinterpret_cast<f32x4*>(Bs + b_row * LDT + b_kk) = vb;
     };
     f32x4 va = load_a(kbeg), vb = load_b(kbeg);
+    stage(0, va, vb);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage(va, vb);
-        __syncthreads();
-        if (k0 + BK < kend) { va = load_a(k0 + BK); vb = load_b(k0 + BK); }     // in flight during the MFMAs
+        const bool more = k0 + BK < kend;
+        if (more) { va = load_a(k0 + BK); vb = load_b(k0 + BK); }              // in flight during the MFMAs
+        const float* As = As2[cur];
+        const float* Bs = Bs2[cur];
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + (wn + li) * LDT + 8 * h);
@@ -109,7 +115,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc, 0, 0, 0);
+        if (more) stage(cur ^ 1, va, vb);       // the other buffer: nobody reads it before the barrier
         __syncthreads();
+        cur ^= 1;
     }
     // accumulator layout of 32x32: lane (h, j) register r holds row 8*(r/4) + 4h + r%4 of column j
     const int n = n0 + wn + li;
