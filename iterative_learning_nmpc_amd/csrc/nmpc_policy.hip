@@ -35,18 +35,22 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 // k terms is irrelevant as long as A and B agree), eight MFMAs per slice.
 // VEC = false: loads are guarded element-wise (K = 47, N = 12 ... are not tile multiples; rows of X
 // are not 16 B aligned).  VEC = true (M, N multiples of 64, K of 16, leading dimensions multiples of
-// 4): 16 B global loads without guards.  The next K slice is prefetched into registers while the
-// current one is multiplied.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
+// 4): 16 B global loads without guards.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
 // batch and have few output tiles: 64 at hidden = 512, 8 for the input and output layers): the
 // partial products are added to C with float atomics, C zeroed by the caller.
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
+
+// The K loop advances KS slices at a time: their 2 x KS 16 B loads per thread are issued together one
+// iteration ahead, so a global-memory round trip (~1 us) is paid once per KS x 8 MFMAs instead of once
+// per 8 (with single slices the loop ran at memory latency: 15 us for a GEMM whose MFMAs take 7).
+constexpr int KS = 4;
 
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                    int ldc, const float* __restrict__ bias) {
-    __shared__ __attribute__((aligned(16))) float As2[2][BM * LDT];    // double-buffered: one barrier per slice
-    __shared__ __attribute__((aligned(16))) float Bs2[2][BN * LDT];
+    __shared__ __attribute__((aligned(16))) float As[KS][BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[KS][BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = 32 * (w >> 1), wn = 32 * (w & 1);
@@ -62,16 +66,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     // memory, (row .. row+3, kk) if the rows are
     const int a_row = TA ? 4 * (tid & 15) : tid >> 2, a_kk = TA ? tid >> 4 : 4 * (tid & 3);
     const int b_row = TB ? 4 * (tid & 15) : tid >> 2, b_kk = TB ? tid >> 4 : 4 * (tid & 3);
-    auto load_a = [&](int k0) -> f32x4 {
+    auto load_a = [&](int k0) -> f32x4 {          // slice starting at k0 (zeros past kend)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if constexpr (VEC) {
-            v = TA ? *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + a_kk) * lda + m0 + a_row)
-                   : *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + a_row) * lda + k0 + a_kk);
+            if (k0 < kend)
+                v = TA ? *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + a_kk) * lda + m0 + a_row)
+                       : *reinterpret_cast<const f32x4*>(A + (size_t)(m0 + a_row) * lda + k0 + a_kk);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + a_row + (TA ? e : 0), k = k0 + a_kk + (TA ? 0 : e);
-                if (m < M && k < K) v[e] = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+                if (m < M && k < kend) v[e] = TA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
             }
         }
         return v;
@@ -79,45 +84,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     auto load_b = [&](int k0) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if constexpr (VEC) {
-            v = TB ? *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + b_kk) * ldb + n0 + b_row)
-                   : *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + b_row) * ldb + k0 + b_kk);
+            if (k0 < kend)
+                v = TB ? *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + b_kk) * ldb + n0 + b_row)
+                       : *reinterpret_cast<const f32x4*>(B + (size_t)(n0 + b_row) * ldb + k0 + b_kk);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + b_row + (TB ? e : 0), k = k0 + b_kk + (TB ? 0 : e);
-                if (n < N && k < K) v[e] = TB ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
+                if (n < N && k < kend) v[e] = TB ? B[(size_t)k * ldb + n] : B[(size_t)n * ldb + k];
             }
         }
         return v;
     };
-    auto stage = [&](int buf, f32x4 va, f32x4 vb) {
-        float* As = As2[buf];
-        float* Bs = Bs2[buf];
-        if (TA) { for (int e = 0; e < 4; ++e) As[(a_row + e) * LDT + a_kk] = va[e]; }
-        else *reinterpret_cast<f32x4*>(As + a_row * LDT + a_kk) = va;
-        if (TB) { for (int e = 0; e < 4; ++e) Bs[(b_row + e) * LDT + b_kk] = vb[e]; }
-        else *reinterpret_cast<f32x4*>(Bs + b_row * LDT + b_kk) = vb;
+    f32x4 va[KS], vb[KS];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { va[j] = load_a(k0 + j * BK); vb[j] = load_b(k0 + j * BK); }
     };
-    f32x4 va = load_a(kbeg), vb = load_b(kbeg);
-    stage(0, va, vb);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) { va = load_a(k0 + BK); vb = load_b(k0 + BK); }              // in flight during the MFMAs
-        const float* As = As2[cur];
-        const float* Bs = Bs2[cur];
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + (wm + li) * LDT + 8 * h + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + (wn + li) * LDT + 8 * h);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs + (wn + li) * LDT + 8 * h + 4);
+    auto stage = [&]() {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc, 0, 0, 0);
-        if (more) stage(cur ^ 1, va, vb);       // the other buffer: nobody reads it before the barrier
+        for (int j = 0; j < KS; ++j) {
+            if (TA) { for (int e = 0; e < 4; ++e) As[j][(a_row + e) * LDT + a_kk] = va[j][e]; }
+            else *reinterpret_cast<f32x4*>(As[j] + a_row * LDT + a_kk) = va[j];
+            if (TB) { for (int e = 0; e < 4; ++e) Bs[j][(b_row + e) * LDT + b_kk] = vb[j][e]; }
+            else *reinterpret_cast<f32x4*>(Bs[j] + b_row * LDT + b_kk) = vb[j];
+        }
+    };
+    constexpr int STEP = BK * KS;
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += STEP) {
+        stage();
         __syncthreads();
-        cur ^= 1;
+        if (k0 + STEP < kend) fetch(k0 + STEP);                   // in flight during the MFMAs of this step
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            if (k0 + j * BK < kend) {                             // block-uniform
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(As[j] + (wm + li) * LDT + 8 * h);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(As[j] + (wm + li) * LDT + 8 * h + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs[j] + (wn + li) * LDT + 8 * h);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bs[j] + (wn + li) * LDT + 8 * h + 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
     }
     // accumulator layout of 32x32: lane (h, j) register r holds row 8*(r/4) + 4h + r%4 of column j
     const int n = n0 + wn + li;
