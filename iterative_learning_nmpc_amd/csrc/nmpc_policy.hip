@@ -233,19 +233,28 @@ __global__ void bn_relu_kernel(size_t n, int H, const float* __restrict__ Z, con
     out[i] = y > 0.0f ? y : 0.0f;
 }
 
-// L1 loss: dP = sign(P - Y) / n ; loss += sum |P - Y| / n   (nn.L1Loss, mean reduction)
-__global__ void l1_kernel(size_t n, const float* __restrict__ P, const float* __restrict__ Y, float* __restrict__ dP,
-                          float* __restrict__ loss) {
+// L1 loss: dP = sign(P - Y) / n ; loss += sum |P - Y| / n   (nn.L1Loss, mean reduction); and the bias
+// gradient of the output layer, the column sums of dP, added to grad_b (zeroed by the caller) through
+// per-block LDS bins (n_out <= 256)
+__global__ __launch_bounds__(256) void l1_kernel(size_t n, int n_out, const float* __restrict__ P, const float* __restrict__ Y,
+                                                 float* __restrict__ dP, float* __restrict__ loss, float* __restrict__ grad_b) {
+    __shared__ float bins[256];
+    bins[threadIdx.x] = 0.0f;
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     float a = 0.0f;
     if (i < n) {
         const float d = P[i] - Y[i];
         a = fabsf(d) / (float)n;
-        dP[i] = (d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f) / (float)n;
+        const float g = (d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f) / (float)n;
+        dP[i] = g;
+        if (g != 0.0f) atomicAdd(&bins[i % n_out], g);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if (loss && (threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(loss, a);
+    __syncthreads();
+    if ((int)threadIdx.x < n_out && bins[threadIdx.x] != 0.0f) atomicAdd(grad_b + threadIdx.x, bins[threadIdx.x]);
 }
 
 // Backward through ReLU and BatchNorm, pass 1: D <- D * (y > 0) in place; per feature and row chunk
@@ -537,6 +546,7 @@ extern "C" {
 int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handle) {
     if (!dims || !handle) return pfail(nullptr, NMPC_E_ARG, "null argument");
     *handle = nullptr;
+    if (dims->n_out > 256) return pfail(nullptr, NMPC_E_ARG, "n_out <= 256");
     if (dims->n_in < 1 || dims->n_out < 1 || dims->hidden < 1 || dims->n_hidden < 1 || dims->n_hidden > 16 || dims->batch_max < 1)
         return pfail(nullptr, NMPC_E_ARG, "need n_in, n_out, hidden, batch_max >= 1 and 1 <= n_hidden <= 16");
     Policy* p = new Policy();
@@ -673,11 +683,11 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     if (pred) PTRY(p, hipMemcpyAsync(pred, p->pred, (size_t)B * no * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (loss) PTRY(p, hipMemsetAsync(loss, 0, sizeof(float), st));
     const size_t np_ = (size_t)B * no;
-    hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, p->pred, Y, p->dpred, loss);
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, no, p->pred, Y, p->dpred, loss,
+                       p->grad + p->ob[L]);
     // output layer: dW = dP' a_L, db = colsum dP, d = dP W
     const float* aL = p->act + (size_t)(L - 1) * p->d.batch_max * H;
     gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr, SPLIT_K);
-    colsum(p, st, B, no, p->dpred, p->grad + p->ob[L]);
     float* d = p->dbuf[0];
     float* dn = p->dbuf[1];
     gemm<false, true>(st, B, H, no, p->dpred, no, p->theta + p->oW[L], H, d, H, nullptr);
