@@ -233,12 +233,13 @@ __global__ void bn_relu_kernel(size_t n, int H, const float* __restrict__ Z, con
     out[i] = y > 0.0f ? y : 0.0f;
 }
 
-// L1 loss: dP = sign(P - Y) / n ; loss += sum |P - Y| / n   (nn.L1Loss, mean reduction); and the bias
+// L1 loss: dP = sign(P - Y) / n ; loss_part[block] = sum |P - Y| / n over the block (nn.L1Loss, mean
+// reduction; adam_kernel adds the blocks up); and the bias
 // gradient of the output layer, the column sums of dP, added to grad_b (zeroed by the caller) through
 // per-block LDS bins (n_out <= 256)
 __global__ __launch_bounds__(256) void l1_kernel(size_t n, int n_out, const float* __restrict__ P, const float* __restrict__ Y,
-                                                 float* __restrict__ dP, float* __restrict__ loss, float* __restrict__ grad_b) {
-    __shared__ float bins[256];
+                                                 float* __restrict__ dP, float* __restrict__ loss_part, float* __restrict__ grad_b) {
+    __shared__ float bins[256], wsum[4];
     bins[threadIdx.x] = 0.0f;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,8 +253,9 @@ __global__ __launch_bounds__(256) void l1_kernel(size_t n, int n_out, const floa
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (loss && (threadIdx.x & 63) == 0 && a != 0.0f) atomicAdd(loss, a);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
     __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     if ((int)threadIdx.x < n_out && bins[threadIdx.x] != 0.0f) atomicAdd(grad_b + threadIdx.x, bins[threadIdx.x]);
 }
 
@@ -348,22 +350,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int H, float* 
     if (g == 0 && f < H) part_b[(size_t)blockIdx.y * H + f] = red[0][fl] + red[1][fl] + red[2][fl] + red[3][fl];
 }
 
-// bias gradients of all hidden layers from their partial sums: grad[ob[l] + f] = sum_c part_b[l][c][f]
-__global__ void bias_grad_final_kernel(int H, const float* __restrict__ part_b, float* __restrict__ grad,
-                                       const unsigned long long* __restrict__ ob) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
-    if (f >= H) return;
-    float s = 0.0f;
-    for (int c = 0; c < RCHUNK; ++c) s += part_b[((size_t)l * RCHUNK + c) * H + f];
-    grad[ob[l] + f] = s;
-}
-
-// torch.optim.Adam, defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay); c1 = 1 - b1^t, c2 = 1 - b2^t
-__global__ void adam_kernel(size_t n, float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float lr, float c1, float c2) {
+// torch.optim.Adam, defaults (betas 0.9 / 0.999, eps 1e-8, no weight decay); c1 = 1 - b1^t, c2 = 1 - b2^t.
+// The last kernel of a step also ties up its loose ends (a launch each otherwise):
+//   * the bias gradients in front of a BatchNorm arrive as partial column sums part_b[l][chunk][f]
+//     (bn_bwd_apply_kernel) and are added up here by the threads that own those entries;
+//   * grad is left zeroed for the next step (the split-K GEMMs and l1_kernel accumulate into it);
+//   * block 0 adds up the per-block partial losses of l1_kernel.
+struct AdamTail {
+    const float* part_b;                 // nullptr without BatchNorm
+    unsigned long long ob[16];           // offsets of the hidden layers' biases in theta
+    int L, H;
+    const float* loss_part;              // per-block partial losses of l1_kernel
+    int n_loss_part;
+    float* loss;                         // may be null
+};
+__global__ void adam_kernel(size_t n, float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float c1, float c2, const AdamTail t) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && t.loss) {
+        float s = 0.0f;
+        for (int b = 0; b < t.n_loss_part; ++b) s += t.loss_part[b];
+        t.loss[0] = s;
+    }
     if (i >= n) return;
-    const float gi = g[i];
+    float gi = g[i];
+    if (t.part_b) {
+        for (int l = 0; l < t.L; ++l) {
+            if (i >= t.ob[l] && i < t.ob[l] + (size_t)t.H) {
+                const size_t f = i - t.ob[l];
+                gi = 0.0f;
+                for (int c = 0; c < RCHUNK; ++c) gi += t.part_b[((size_t)l * RCHUNK + c) * t.H + f];
+            }
+        }
+    }
+    g[i] = 0.0f;
     const float mi = ADAM_B1 * m[i] + (1.0f - ADAM_B1) * gi;
     const float vi = ADAM_B2 * v[i] + (1.0f - ADAM_B2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -470,7 +490,8 @@ struct Policy {
     float *pred = nullptr, *dpred = nullptr;
     float *part = nullptr;     // partial column sums [2][RCHUNK][max(hidden, n_out)]
     float *part_b = nullptr;   // partial bias-gradient sums of the hidden layers [L][RCHUNK][hidden]
-    unsigned long long* ob_dev = nullptr;   // ob[] on the device
+    float *loss_part = nullptr;   // per-block partial losses of l1_kernel
+    bool grad_dirty = false;   // a step that did not reach adam_kernel left grad non-zero
     long long step = 0;
     std::string err;
 };
@@ -572,7 +593,7 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->act, (size_t)L * Bm * H}, {&p->z, (size_t)L * Bm * H}, {&p->dbuf[0], Bm * wide}, {&p->dbuf[1], Bm * wide},
         {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out},
         {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)},
-        {&p->part_b, (size_t)L * RCHUNK * H}};
+        {&p->part_b, (size_t)L * RCHUNK * H}, {&p->loss_part, (Bm * dims->n_out + 255) / 256 + 1}};
     hipError_t e = hipSetDevice(device_id);
     for (auto& b : bufs) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b.ptr), b.n * sizeof(float));
@@ -584,17 +605,6 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         delete p;
         return NMPC_E_HIP;
     }
-    {   // bias offsets of the hidden layers for bias_grad_final_kernel
-        unsigned long long ob[16];
-        for (int l = 0; l < L; ++l) ob[l] = p->ob[l];
-        e = hipMalloc(reinterpret_cast<void**>(&p->ob_dev), sizeof(ob));
-        if (e == hipSuccess) e = hipMemcpy(p->ob_dev, ob, sizeof(ob), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            g_policy_create_error = std::string("nmpc_policy_create: ") + hipGetErrorString(e);
-            nmpc_policy_destroy(p);
-            return NMPC_E_HIP;
-        }
-    }
     *handle = p;
     return NMPC_OK;
 }
@@ -604,9 +614,8 @@ void nmpc_policy_destroy(void* handle) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
-                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b};
+                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part};
     for (float* q : all) if (q) (void)hipFree(q);
-    if (p->ob_dev) (void)hipFree(p->ob_dev);
     delete p;
 }
 
@@ -678,12 +687,12 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     PTRY(p, hipSetDevice(p->device));
     const int L = p->d.n_hidden, H = p->d.hidden, no = p->d.n_out;
     const bool bn = p->d.batch_norm != 0;
-    PTRY(p, hipMemsetAsync(p->grad, 0, p->n_theta * sizeof(float), st));     // split-K GEMMs accumulate into it
+    if (p->grad_dirty) PTRY(p, hipMemsetAsync(p->grad, 0, p->n_theta * sizeof(float), st));   // normally left zero by adam_kernel
+    p->grad_dirty = true;
     forward(p, B, X, p->pred, true, st);
     if (pred) PTRY(p, hipMemcpyAsync(pred, p->pred, (size_t)B * no * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (loss) PTRY(p, hipMemsetAsync(loss, 0, sizeof(float), st));
     const size_t np_ = (size_t)B * no;
-    hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, no, p->pred, Y, p->dpred, loss,
+    hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, no, p->pred, Y, p->dpred, p->loss_part,
                        p->grad + p->ob[L]);
     // output layer: dW = dP' a_L, db = colsum dP, d = dP W
     const float* aL = p->act + (size_t)(L - 1) * p->d.batch_max * H;
@@ -712,13 +721,16 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
             float* t = d; d = dn; dn = t;
         }
     }
-    if (bn)
-        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((H + 255) / 256, L), dim3(256), 0, st, H, p->part_b, p->grad,
-                           p->ob_dev);
     p->step += 1;
     const float c1 = 1.0f - std::pow(ADAM_B1, (float)p->step), c2 = 1.0f - std::pow(ADAM_B2, (float)p->step);
+    AdamTail tail{};
+    tail.part_b = bn ? p->part_b : nullptr;
+    for (int l = 0; l < L; ++l) tail.ob[l] = p->ob[l];
+    tail.L = L; tail.H = H;
+    tail.loss_part = p->loss_part; tail.n_loss_part = (int)blocks_for(np_); tail.loss = loss;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(p->n_theta)), dim3(256), 0, st, p->n_theta, p->theta, p->grad,
-                       p->m, p->v, lr, c1, c2);
+                       p->m, p->v, lr, c1, c2, tail);
+    p->grad_dirty = false;
     PTRY(p, hipGetLastError());
     return NMPC_OK;
 }
