@@ -183,3 +183,97 @@ def test_tracking_error_reproduces_reference_ood_selection(oracle64, golden_dir)
     s2 = g["s_pert"].copy(); s2[:, :, 0] = -7.0
     assert np.array_equal(oracle64.tracking_error(s2, g["s_nom"]), err)
     assert np.allclose(err, np.linalg.norm(g["s_pert"][:, :, 1:] - g["s_nom"][None, :, 1:], axis=-1), rtol=1e-14)
+
+
+def _scipy_nlp(o, model_id, w, b, N):
+    """The OCP of problem b as a generic NLP for scipy (variables z = [X(1..N), U(0..N-1)], x_0 fixed):
+    equality constraints = the oracle's own dynamics, inequalities = its constraint rows."""
+    from scipy.optimize import minimize
+    nx, nu, np_, ng = o.dims(model_id)
+    W, We = np.asarray(w.W, float), np.asarray(w.W_e, float)
+    yref = w.yref[b] if w.yref.ndim == 3 else np.repeat(w.yref[b][None], N, 0)
+    par = (lambda k: w.params[b, k]) if np_ > 0 else (lambda k: None)
+    unpack = lambda z: (np.vstack([w.x0[b], z[:N * nx].reshape(N, nx)]), z[N * nx:].reshape(N, nu))
+
+    def cost(z):
+        X, U = unpack(z)
+        e = np.hstack([X[:N], U]) - yref
+        return 0.5 * (W * e * e).sum() + 0.5 * (We * (X[N] - w.yref_e[b]) ** 2).sum()
+
+    def defects(z):
+        X, U = unpack(z)
+        return np.concatenate([o.dynamics(model_id, w.mp, X[k], U[k], par(k), jac=False) - X[k + 1] for k in range(N)])
+
+    def ineq(z):                                     # scipy convention: >= 0
+        X, U = unpack(z)
+        out = []
+        for k in range(N):
+            G, h, act = o.constraints(model_id, w.mp, par(k))
+            out.append((h - G @ U[k])[act > 0])
+        return np.concatenate(out) if out else np.zeros(0)
+
+    z0 = np.concatenate([w.X[b, 1:N + 1].ravel(), w.U[b, :N].ravel()]).astype(float)
+    cons = [dict(type="eq", fun=defects)]
+    if ineq(z0).size:
+        cons.append(dict(type="ineq", fun=ineq))
+    r = minimize(cost, z0, method="SLSQP", constraints=cons, options=dict(maxiter=500, ftol=1e-14))
+    assert r.success, r.message
+    return unpack(r.x)
+
+
+def _truncate(w, N):
+    """The first N stages of a workload (shorter horizon for the generic solver)."""
+    import copy
+    v = copy.copy(w)
+    v.N = N
+    v.X, v.U, v.params = w.X[:, :N + 1].copy(), w.U[:, :N].copy(), w.params[:, :N + 1].copy()
+    if w.yref.ndim == 3:
+        v.yref = w.yref[:, :N].copy()
+    return v
+
+
+def test_converged_oracle_solution_is_the_optimum_of_an_independent_nlp_solver(oracle64):
+    """Cross-check against solvers that share nothing with the oracle's algorithm (scipy BVLS and SLSQP,
+    active-set methods): with the barrier driven to zero (tau_min -> 0, many interior-point and SQP
+    iterations) the oracle's multiple-shooting Gauss-Newton SQP + Riccati interior point reaches the
+    same constrained optimum -- for the box-constrained double integrator (a QP with active bounds)
+    and for the centroidal model with an active friction pyramid (a nonlinear programme)."""
+    o = oracle64
+    # box-constrained double integrator, bounds active: condensed to a bounded least-squares problem in U
+    # and handed to scipy's BVLS (an active-set method on the normal equations)
+    from scipy.optimize import lsq_linear
+    w = _truncate(wl.double_integrator(B=2, N=20, seed=1, umax=1.0), 8)
+    N, nx, nu = w.N, 4, 2
+    X, U, st, _ = o.solve_batch(w.model_id, w.N, w.mp, o.opt(max_sqp_iter=4, n_ipm=60, tau_min=1e-10, mu0=1.0, reg=0.0, reg_e=0.0,
+                                                             yref_per_stage=int(w.yref.ndim == 3)),
+                                w.W, w.W_e, w.x0, w.yref, w.yref_e, w.params, w.X, w.U)
+    _, A, Bm = o.dynamics(0, w.mp, np.zeros(4), np.zeros(2))
+    Wd, Wed = np.sqrt(np.asarray(w.W, float)), np.sqrt(np.asarray(w.W_e, float))
+    for b in range(2):
+        Sx = [np.linalg.matrix_power(A, k) @ w.x0[b] for k in range(N + 1)]       # x_k = A^k x0 + sum_j A^(k-1-j) B u_j
+        Su = np.zeros((N + 1, nx, N * nu))
+        for k in range(1, N + 1):
+            for j in range(k):
+                Su[k][:, j * nu:(j + 1) * nu] = np.linalg.matrix_power(A, k - 1 - j) @ Bm
+        yref = w.yref[b] if w.yref.ndim == 3 else np.repeat(w.yref[b][None], N, 0)
+        rows, rhs = [], []
+        for k in range(N):
+            rows.append(Wd[:nx, None] * Su[k]); rhs.append(Wd[:nx] * (yref[k, :nx] - Sx[k]))
+            E = np.zeros((nu, N * nu)); E[:, k * nu:(k + 1) * nu] = np.eye(nu)
+            rows.append(Wd[nx:, None] * E); rhs.append(Wd[nx:] * yref[k, nx:])
+        rows.append(Wed[:, None] * Su[N]); rhs.append(Wed * (w.yref_e[b] - Sx[N]))
+        r = lsq_linear(np.vstack(rows), np.concatenate(rhs), bounds=(-1.0, 1.0), method="bvls", tol=1e-14)
+        Us = r.x.reshape(N, nu)
+        assert r.status > 0 and np.abs(np.abs(Us).max() - 1.0) < 1e-9          # the bound is active in the optimum
+        assert np.abs(U[b] - Us).max() < 1e-7
+    # centroidal model, low friction -> pyramid active, nonlinear dynamics
+    w = _truncate(wl.centroidal_trot(B=1, N=50, seed=3), 4)
+    w.mp = w.mp.copy(); w.mp[6] = 0.15
+    w.yref = w.yref.copy(); w.yref[:, :, 6] = 0.8                          # ask for forward speed: needs tangential force
+    X, U, st, _ = o.solve_batch(w.model_id, w.N, w.mp, o.opt(max_sqp_iter=30, n_ipm=60, tau_min=1e-10, mu0=1.0, nlp_tol=1e-9,
+                                                             reg=w.meta["reg"], reg_e=w.meta["reg_e"], yref_per_stage=1),
+                                w.W, w.W_e, w.x0, w.yref, w.yref_e, w.params, w.X, w.U)
+    Xs, Us = _scipy_nlp(o, 1, w, 0, w.N)
+    G, h, act = o.constraints(1, w.mp, w.params[0, 0])
+    assert ((G @ Us[0] - h)[act > 0] > -1e-6).any()                      # the pyramid is active in the optimum
+    assert np.abs(U[0] - Us).max() < 1e-5 * np.abs(Us).max() and np.abs(X[0] - Xs).max() < 1e-5      # measured 1e-6 / 8e-7
