@@ -194,6 +194,72 @@ def policy_mode(a, world, rank, dev, dist):
             "cpu_baseline": cpu}), flush=True)
 
 
+def database_mode(a, world, rank, dev, dist):
+    """Dataset side of the learning update: a step = `Database.calc_input_mean_std` over a state
+    table of a.database rows x 44 columns per GPU (database.py:208-255; the reference recomputes it after every
+    append, cfgs/iter_locosafedagger.yaml:61 sizes the table at 1e7 rows) + one normalised batch of 1024
+    (`__getitem__` x 1024).  HBM-bound: two passes over the table."""
+    from iterative_learning_nmpc_amd.database import DeviceDatabase
+    rows, n_state, batch = a.database, 44, 1024
+    db = DeviceDatabase(rows, n_state=n_state, n_action=12, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    chunk = 1 << 20
+    for r0 in range(0, rows, chunk):                      # fill the tables in place (append = the same kernels, timed below)
+        n = min(chunk, rows - r0)
+        db.tables["states"][r0:r0 + n] = torch.randn(n, n_state, generator=g, device=dev) * 2.0 + 1.0
+    db.length, db.has["vc_goals"] = rows, True
+    idx = torch.randint(0, rows, (batch,), generator=g, device=dev, dtype=torch.int32)
+
+    def step():
+        db.calc_input_mean_std()
+        return db.batch(idx)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        x, y = step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    ms = e0.elapsed_time(e1) / a.steps
+    nbytes = 2.0 * rows * n_state * 4                      # the table is read once per pass; everything else is KB
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle.database_oracle import DatabaseOracle  # the checker, timed as the reported CPU baseline
+        sample = min(rows, 2_000_000)
+        o = DatabaseOracle(sample)
+        o.rows["states"] = db.tables["states"][:sample].cpu().numpy().astype(np.float64); o.length = sample
+        o.calc_input_mean_std()
+        n_rep, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 10.0:
+            o.calc_input_mean_std(); n_rep += 1
+        cpu = {"value": n_rep * sample / (time.perf_counter() - t1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{n_rep} x mean/std over the first {sample} rows, float64 numpy oracle"}
+    if rank == 0:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "database rows/sec through mean/std + batch assembly (44-column state table)",
+            "value": world * rows * a.steps / el, "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"database statistics: {rows} rows x {n_state} fp32 per GPU, batch {batch}"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": None, "kernel": "colstat_partial_kernel (2 passes)", "kernel_ms": ms,
+                         "bytes_per_step": nbytes},
+            "cpu_baseline": cpu}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +276,8 @@ def main():
                          "on the device, tracking error vs the nominal rollout, all-gather over the ranks")
     ap.add_argument("--policy", type=int, default=0,
                     help="extra mode (not the headline metric): training steps of the policy network on a batch of this size")
+    ap.add_argument("--database", type=int, default=0,
+                    help="extra mode (not the headline metric): mean/std + batch assembly over a state table of this many rows")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,8 +293,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if a.rollouts or a.policy:
-        (rollout_mode if a.rollouts else policy_mode)(a, world, rank, dev, dist)
+    if a.rollouts or a.policy or a.database:
+        (rollout_mode if a.rollouts else policy_mode if a.policy else database_mode)(a, world, rank, dev, dist)
         if dist:
             dist.destroy_process_group()
         return

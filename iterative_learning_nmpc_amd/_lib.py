@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NMPC_HIP_LIB") or os.path.join(_HERE, "libnmpc_hip.so
 NMPC_OK = 0
 STATUS_NAMES = {0: "ok", 1: "nan", 2: "max_iter", 3: "min_step", 4: "qp_failure"}
 
-# every symbol include/nmpc.h declares: name -> (restype, argtypes)
+# every symbol include/*.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "nmpc_model_dims": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "nmpc_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
@@ -45,6 +45,13 @@ SIGNATURES = {
     "nmpc_policy_train_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "nmpc_weighted_sample": (c_int, [c_void_p, ctypes.c_longlong, c_int, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p]),
     "nmpc_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    # include/nmpc_dataset.h
+    "nmpc_dataset_last_error": (ctypes.c_char_p, []),
+    "nmpc_ring_append": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
+    "nmpc_column_stats_scratch": (ctypes.c_size_t, [c_int]),
+    "nmpc_column_stats": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_assemble_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }

@@ -20,7 +20,7 @@ def lib():
 
 def test_header_symbols_are_exported_and_bound(lib):
     from iterative_learning_nmpc_amd import _lib
-    header = open(os.path.join(ROOT, "include", "nmpc.h")).read() + open(os.path.join(ROOT, "include", "nmpc_policy.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     declared = set(re.findall(r"\b(nmpc_[a-z_]+)\s*\(", header))
     assert declared, "no declarations found"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
@@ -46,6 +46,22 @@ def test_create_rejects_bad_dims_on_the_host(lib):
         assert lib.nmpc_create(ctypes.byref(dims), 0, ctypes.byref(h)) == -1
         assert not h.value and lib.nmpc_last_error(None)
     assert lib.nmpc_create(None, 0, ctypes.byref(h)) == -1
+
+
+def test_dataset_calls_reject_bad_arguments_on_the_host(lib):
+    """include/nmpc_dataset.h: argument checks come before any launch (no GPU needed)."""
+    one = ctypes.c_void_p(8)                     # a non-null placeholder, never dereferenced on these paths
+    assert lib.nmpc_ring_append(None, 4, 1, one, 8, 0, None) == -1
+    assert lib.nmpc_ring_append(one, 4, 1, one, 8, 8, None) == -1            # first_slot outside the ring
+    assert lib.nmpc_ring_append(one, 0, 1, one, 8, 0, None) == -1
+    assert lib.nmpc_ring_append(None, 4, 0, None, 8, 0, None) == 0           # nothing to append
+    assert lib.nmpc_column_stats(one, 10, 65, one, one, one, None) == -1     # cols <= 64
+    assert lib.nmpc_column_stats(one, 0, 4, one, one, one, None) == -1
+    assert b"cols" in lib.nmpc_dataset_last_error()
+    assert lib.nmpc_column_stats_scratch(44) >= 44 and lib.nmpc_column_stats_scratch(0) == 0
+    assert lib.nmpc_assemble_batch(one, 44, one, None, 1, one, 3, None, None, one, 12, 10, one, 4, one, one, None) == -1
+    assert lib.nmpc_assemble_batch(one, 44, None, None, 1, None, 3, None, None, one, 12, 10, one, 4, one, one, None) == -1
+    assert lib.nmpc_assemble_batch(None, 44, None, None, 1, None, 0, None, None, None, 0, 10, None, 0, None, None, None) == 0
 
 
 def test_python_layer_refuses_to_run_without_a_device():
