@@ -7,6 +7,7 @@
 // the state table is 1.76 GB: it stays in HBM next to the rollouts that fill it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -50,9 +51,8 @@ __global__ __launch_bounds__(256) void colstat_partial_kernel(const float* __res
         if ((int)threadIdx.x < cols) mean_s[threadIdx.x] = mean[threadIdx.x];
         __syncthreads();
     }
-    const long long total = rows * cols;
     const long long super = 64LL * cols;
-    const long long n_super = (total + super - 1) / super;
+    const long long n_super = rows / 64;                          // full super rows; the < 64 rows left go to block 0
     const int step = 64 % cols;
 
     double acc[NACC];
@@ -60,34 +60,27 @@ __global__ __launch_bounds__(256) void colstat_partial_kernel(const float* __res
     for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
 
     for (long long sr = (long long)blockIdx.x * 4 + wave; sr < n_super; sr += (long long)gridDim.x * 4) {
-        const long long base = sr * super + lane;
-        const bool full = (sr + 1) * super <= total;
+        const float* __restrict__ p = data + sr * super;          // wave-uniform base, 32-bit lane offsets
         float v[NACC];
-        if (full) {
 #pragma unroll
-            for (int j = 0; j < NACC; ++j)
-                if (j < cols) v[j] = data[base + 64 * j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NACC; ++j)
-                if (j < cols) v[j] = (base + 64 * j < total) ? data[base + 64 * j] : 0.0f;
-        }
+        for (int j = 0; j < NACC; ++j)
+            if (j < cols) v[j] = p[lane + 64 * j];
         int c = lane % cols;
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
             if (j < cols) {
                 if (PASS == 0) {
-                    if (full || base + 64 * j < total) acc[j] += (double)v[j];
+                    acc[j] += (double)v[j];
                 } else {
                     const double d = (double)v[j] - mean_s[c];
-                    if (full || base + 64 * j < total) acc[j] += d * d;
+                    acc[j] += d * d;
                     c += step;
                     if (c >= cols) c -= cols;
                 }
             }
         }
     }
-    // waves in order, then the 64 slots of a column in order
+    // waves in order, then the 64 slots of a column in order, then (block 0) the rows beyond the last super row
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -99,6 +92,12 @@ __global__ __launch_bounds__(256) void colstat_partial_kernel(const float* __res
     if ((int)threadIdx.x < cols) {
         double s = 0.0;
         for (int r = 0; r < 64; ++r) s += flat[threadIdx.x + cols * r];
+        if (blockIdx.x == 0) {
+            for (long long r = n_super * 64; r < rows; ++r) {
+                const double x = (double)data[r * cols + threadIdx.x];
+                s += PASS == 0 ? x : (x - mean_s[threadIdx.x]) * (x - mean_s[threadIdx.x]);
+            }
+        }
         part[(size_t)blockIdx.x * cols + threadIdx.x] = s;
     }
 }
@@ -172,14 +171,31 @@ int launched() {
     return e == hipSuccess ? NMPC_OK : dfail(NMPC_E_HIP, hipGetErrorString(e));
 }
 
+// One resident round: as many blocks as the device holds at once (a grid-stride kernel launched wider
+// than that runs a second, mostly idle round), at most STAT_BLOCKS_MAX (the scratch size).
+template <int COLS, int PASS>
+int resident_blocks() {
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, colstat_partial_kernel<COLS, PASS>, 256, 0) != hipSuccess ||
+            cus < 1 || per_cu < 1)
+            return STAT_BLOCKS_MAX;
+        cached = std::min(STAT_BLOCKS_MAX, cus * per_cu);
+    }
+    return cached;
+}
+
 template <int COLS>
 void column_stats(hipStream_t st, const float* data, long long rows, int cols, double* mean, double* std_out, double* part) {
-    const long long n_super = (rows + 63) / 64;
-    const int blocks = (int)std::min<long long>(STAT_BLOCKS_MAX, (n_super + 3) / 4);
-    hipLaunchKernelGGL((colstat_partial_kernel<COLS, 0>), dim3(blocks), dim3(256), 0, st, data, rows, cols, nullptr, part);
-    hipLaunchKernelGGL((colstat_final_kernel<0>), dim3(1), dim3(64 * STAT_SEGS), 0, st, part, blocks, cols, rows, mean);
-    hipLaunchKernelGGL((colstat_partial_kernel<COLS, 1>), dim3(blocks), dim3(256), 0, st, data, rows, cols, mean, part);
-    hipLaunchKernelGGL((colstat_final_kernel<1>), dim3(1), dim3(64 * STAT_SEGS), 0, st, part, blocks, cols, rows, std_out);
+    const long long need = std::max<long long>(1, (rows / 64 + 3) / 4);      // blocks that have a super row to read
+    const int b0 = (int)std::min<long long>(resident_blocks<COLS, 0>(), need);
+    const int b1 = (int)std::min<long long>(resident_blocks<COLS, 1>(), need);
+    hipLaunchKernelGGL((colstat_partial_kernel<COLS, 0>), dim3(b0), dim3(256), 0, st, data, rows, cols, nullptr, part);
+    hipLaunchKernelGGL((colstat_final_kernel<0>), dim3(1), dim3(64 * STAT_SEGS), 0, st, part, b0, cols, rows, mean);
+    hipLaunchKernelGGL((colstat_partial_kernel<COLS, 1>), dim3(b1), dim3(256), 0, st, data, rows, cols, mean, part);
+    hipLaunchKernelGGL((colstat_final_kernel<1>), dim3(1), dim3(64 * STAT_SEGS), 0, st, part, b1, cols, rows, std_out);
 }
 
 }  // namespace
