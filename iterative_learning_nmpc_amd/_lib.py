@@ -52,6 +52,15 @@ SIGNATURES = {
     "nmpc_column_stats": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nmpc_assemble_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_int, ctypes.c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    # include/nmpc_torque.h
+    "nmpc_torque_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "nmpc_torque_destroy": (None, [c_void_p]),
+    "nmpc_torque_last_error": (ctypes.c_char_p, [c_void_p]),
+    "nmpc_id_torques_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nmpc_pd_torques_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                      c_void_p, c_void_p]),
+    "nmpc_pd_target_action_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                            c_void_p, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
 }
@@ -60,6 +69,14 @@ SIGNATURES = {
 class NmpcPolicyDims(ctypes.Structure):
     _fields_ = [("n_in", c_int), ("n_out", c_int), ("n_hidden", c_int), ("hidden", c_int),
                 ("batch_norm", c_int), ("batch_max", c_int)]
+
+
+class NmpcTreeModel(ctypes.Structure):
+    _fields_ = [("n_joints", c_int), ("n_actuated", c_int), ("n_feet", c_int),
+                ("parent", POINTER(c_int)), ("type", POINTER(c_int)), ("axis", POINTER(c_float)),
+                ("placement", POINTER(c_float)), ("mass", POINTER(c_float)), ("com", POINTER(c_float)),
+                ("inertia", POINTER(c_float)), ("foot_joint", POINTER(c_int)), ("foot_offset", POINTER(c_float)),
+                ("gravity", c_float * 3)]
 
 
 class NmpcRolloutCfg(ctypes.Structure):

@@ -64,6 +64,34 @@ def test_dataset_calls_reject_bad_arguments_on_the_host(lib):
     assert lib.nmpc_assemble_batch(None, 44, None, None, 1, None, 0, None, None, None, 0, 10, None, 0, None, None, None) == 0
 
 
+def test_torque_model_is_validated_on_the_host(lib):
+    """include/nmpc_torque.h: a malformed tree is rejected before any device call."""
+    from iterative_learning_nmpc_amd import _lib
+    import numpy as np
+    n = 3
+    arr = dict(parent=np.array([-1, 0, 1], np.int32), type=np.zeros(n, np.int32), axis=np.tile(np.float32([0, 0, 1]), (n, 1)),
+               placement=np.tile(np.float32([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]), (n, 1)), mass=np.ones(n, np.float32),
+               com=np.zeros((n, 3), np.float32), inertia=np.tile(np.float32([1, 0, 0, 1, 0, 1]), (n, 1)),
+               foot_joint=np.array([2], np.int32), foot_offset=np.zeros((1, 3), np.float32))
+
+    def create(n_act=2, **over):
+        a = {k: np.ascontiguousarray(over.get(k, v)) for k, v in arr.items()}
+        m = _lib.NmpcTreeModel()
+        m.n_joints, m.n_actuated, m.n_feet = n, n_act, 1
+        for k, v in a.items():
+            setattr(m, k, v.ctypes.data_as(ctypes.POINTER(ctypes.c_int if v.dtype == np.int32 else ctypes.c_float)))
+        h = ctypes.c_void_p()
+        return lib.nmpc_torque_create(ctypes.byref(m), 0, ctypes.byref(h)), lib.nmpc_torque_last_error(None)
+
+    assert create(parent=np.array([-1, 2, 1], np.int32)) == (-1, b"parents must come before their children")
+    assert create(type=np.array([0, 2, 0], np.int32))[0] == -1
+    assert create(axis=np.tile(np.float32([0, 0, 2]), (n, 1)))[0] == -1
+    assert create(foot_joint=np.array([3], np.int32))[0] == -1
+    assert create(n_act=4)[0] == -1
+    assert lib.nmpc_torque_create(None, 0, None) == -1
+    assert lib.nmpc_id_torques_batch(None, 1, None, None, None, None, None, None) == -1
+
+
 def test_python_layer_refuses_to_run_without_a_device():
     torch = pytest.importorskip("torch")
     if torch.cuda.is_available():
