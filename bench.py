@@ -260,6 +260,65 @@ def database_mode(a, world, rank, dev, dist):
             "cpu_baseline": cpu}), flush=True)
 
 
+def torque_mode(a, world, rank, dev, dist):
+    """Torque layer: a step = id_torques (dynamics.py:136-163) + PD law (mpc.py:592-599) for
+    a.torques robots per GPU on a declared 18-DoF quadruped tree (the reference's URDF is not in the image)."""
+    from iterative_learning_nmpc_amd.torque import BatchedTorqueLayer
+    from oracle import torque_oracle as to                 # the model builder and, below, the CPU baseline
+    m = to.quadruped_model()
+    L = BatchedTorqueLayer(m.parent, m.jtype, m.axis, m.R_fix, m.p_fix, m.mass, m.com, m.inertia, m.foot_joint, m.foot_offset,
+                           m.nu, gravity=m.gravity, device=dev)
+    B = a.torques
+    g = torch.Generator(device=dev).manual_seed(9 + rank)
+    q, v, acc, qp, vp = (torch.rand(B, m.n, generator=g, device=dev) * 2 - 1 for _ in range(5))
+    f = torch.rand(B, 4, 3, generator=g, device=dev) * 60.0
+
+    def step():
+        return L.compute_pd_torques(q, v, L.id_torques(q, v, acc, f), qp, vp, 44.0, 5.0)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        tau = step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    ms = e0.elapsed_time(e1) / a.steps
+    nbytes = 4.0 * B * (5 * m.n + 12 + 3 * m.nu)           # q, v, a, q_plan, v_plan, f in; tau_ff out + in, tau out
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        n_s = min(B, 256)
+        qh, vh, ah, fh = (t[:n_s].cpu().numpy().astype(np.float64) for t in (q, v, acc, f))
+        n_rep, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 10.0:
+            to.id_torques_batch(m, qh, vh, ah, fh); n_rep += 1
+        cpu = {"value": n_rep * n_s / (time.perf_counter() - t1), "unit": "robots/s", "cores": 1, "kind": "port",
+               "sample": f"{n_rep} x id_torques of the first {n_s} robots, float64 numpy oracle (pure-Python recursion)"}
+    if rank == 0:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "torque layer robots/sec (inverse dynamics with contact forces + PD, 18-DoF tree)",
+            "value": world * B * a.steps / el, "unit": "robots/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"torque layer: {B} robots/GPU, declared quadruped tree", "tau_abs_mean": float(tau.abs().mean().item())},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": None, "kernel": "id_torques_kernel (serial recursion per robot: latency-bound)", "kernel_ms": ms,
+                         "bytes_per_step": nbytes},
+            "cpu_baseline": cpu}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +335,8 @@ def main():
                          "on the device, tracking error vs the nominal rollout, all-gather over the ranks")
     ap.add_argument("--policy", type=int, default=0,
                     help="extra mode (not the headline metric): training steps of the policy network on a batch of this size")
+    ap.add_argument("--torques", type=int, default=0,
+                    help="extra mode (not the headline metric): inverse dynamics + PD for this many robots")
     ap.add_argument("--database", type=int, default=0,
                     help="extra mode (not the headline metric): mean/std + batch assembly over a state table of this many rows")
     a = ap.parse_args()
@@ -293,8 +354,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if a.rollouts or a.policy or a.database:
-        (rollout_mode if a.rollouts else policy_mode if a.policy else database_mode)(a, world, rank, dev, dist)
+    if a.rollouts or a.policy or a.database or a.torques:
+        (rollout_mode if a.rollouts else policy_mode if a.policy else database_mode if a.database else torque_mode)(a, world, rank, dev, dist)
         if dist:
             dist.destroy_process_group()
         return
