@@ -264,13 +264,12 @@ def torque_mode(a, world, rank, dev, dist):
     """Torque layer: a step = id_torques (dynamics.py:136-163) + PD law (mpc.py:592-599) for
     a.torques robots per GPU on a declared 18-DoF quadruped tree (the reference's URDF is not in the image)."""
     from iterative_learning_nmpc_amd.torque import BatchedTorqueLayer
-    from oracle import torque_oracle as to                 # the model builder and, below, the CPU baseline
-    m = to.quadruped_model()
-    L = BatchedTorqueLayer(m.parent, m.jtype, m.axis, m.R_fix, m.p_fix, m.mass, m.com, m.inertia, m.foot_joint, m.foot_offset,
-                           m.nu, gravity=m.gravity, device=dev)
+    tree = wl.quadruped_tree()
+    L = BatchedTorqueLayer(device=dev, **tree)
+    n, nu = len(tree["parent"]), tree["n_actuated"]
     B = a.torques
     g = torch.Generator(device=dev).manual_seed(9 + rank)
-    q, v, acc, qp, vp = (torch.rand(B, m.n, generator=g, device=dev) * 2 - 1 for _ in range(5))
+    q, v, acc, qp, vp = (torch.rand(B, n, generator=g, device=dev) * 2 - 1 for _ in range(5))
     f = torch.rand(B, 4, 3, generator=g, device=dev) * 60.0
 
     def step():
@@ -295,9 +294,11 @@ def torque_mode(a, world, rank, dev, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms = e0.elapsed_time(e1) / a.steps
-    nbytes = 4.0 * B * (5 * m.n + 12 + 3 * m.nu)           # q, v, a, q_plan, v_plan, f in; tau_ff out + in, tau out
+    nbytes = 4.0 * B * (5 * n + 12 + 3 * nu)           # q, v, a, q_plan, v_plan, f in; tau_ff out + in, tau out
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
+        from oracle import torque_oracle as to             # the checker, timed as the reported CPU baseline
+        m = to.TreeModel.from_arrays(tree)
         n_s = min(B, 256)
         qh, vh, ah, fh = (t[:n_s].cpu().numpy().astype(np.float64) for t in (q, v, acc, f))
         n_rep, t1 = 0, time.perf_counter()

@@ -234,29 +234,33 @@ __global__ void bn_relu_kernel(size_t n, int H, const float* __restrict__ Z, con
 }
 
 // L1 loss: dP = sign(P - Y) / n ; loss_part[block] = sum |P - Y| / n over the block (nn.L1Loss, mean
-// reduction; adam_kernel adds the blocks up); and the bias
-// gradient of the output layer, the column sums of dP, added to grad_b (zeroed by the caller) through
-// per-block LDS bins (n_out <= 256)
+// reduction; adam_kernel adds the blocks up); and the bias gradient of the output layer, the column sums of
+// dP.  Every term of such a column sum is +-1/n, so it is accumulated as an INTEGER count of signs
+// (sign_count[n_out], zero on entry, turned into count / n by adam_kernel): exact and independent of the
+// order of the atomics.  With float atomics a balanced column (as many + as -: an exactly zero gradient)
+// came out as 0 or as +-1 ulp depending on the order, and Adam -- whose first steps only look at the sign --
+// moved that bias or not from run to run.
 __global__ __launch_bounds__(256) void l1_kernel(size_t n, int n_out, const float* __restrict__ P, const float* __restrict__ Y,
-                                                 float* __restrict__ dP, float* __restrict__ loss_part, float* __restrict__ grad_b) {
-    __shared__ float bins[256], wsum[4];
-    bins[threadIdx.x] = 0.0f;
+                                                 float* __restrict__ dP, float* __restrict__ loss_part, int* __restrict__ sign_count) {
+    __shared__ int bins[256];
+    __shared__ float wsum[4];
+    bins[threadIdx.x] = 0;
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     float a = 0.0f;
     if (i < n) {
         const float d = P[i] - Y[i];
         a = fabsf(d) / (float)n;
-        const float g = (d > 0.0f ? 1.0f : d < 0.0f ? -1.0f : 0.0f) / (float)n;
-        dP[i] = g;
-        if (g != 0.0f) atomicAdd(&bins[i % n_out], g);
+        const int sgn = d > 0.0f ? 1 : d < 0.0f ? -1 : 0;
+        dP[i] = (float)sgn / (float)n;
+        if (sgn != 0) atomicAdd(&bins[i % n_out], sgn);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = a;
     __syncthreads();
     if (threadIdx.x == 0) loss_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    if ((int)threadIdx.x < n_out && bins[threadIdx.x] != 0.0f) atomicAdd(grad_b + threadIdx.x, bins[threadIdx.x]);
+    if ((int)threadIdx.x < n_out && bins[threadIdx.x] != 0) atomicAdd(sign_count + threadIdx.x, bins[threadIdx.x]);
 }
 
 // Backward through ReLU and BatchNorm, pass 1: D <- D * (y > 0) in place; per feature and row chunk
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int H, float* 
 // The last kernel of a step also ties up its loose ends (a launch each otherwise):
 //   * the bias gradients in front of a BatchNorm arrive as partial column sums part_b[l][chunk][f]
 //     (bn_bwd_apply_kernel) and are added up here by the threads that own those entries;
-//   * grad is left zeroed for the next step (the split-K GEMMs and l1_kernel accumulate into it);
+//   * grad and the sign counts are left zeroed for the next step (the split-K GEMMs and l1_kernel accumulate into them);
 //   * block 0 adds up the per-block partial losses of l1_kernel.
 struct AdamTail {
     const float* part_b;                 // nullptr without BatchNorm
@@ -363,6 +367,10 @@ struct AdamTail {
     const float* loss_part;              // per-block partial losses of l1_kernel
     int n_loss_part;
     float* loss;                         // may be null
+    int* sign_count;                     // l1_kernel's sign counts -> bias gradient of the output layer; zeroed here
+    unsigned long long ob_out;           // offset of that bias in theta
+    int n_out;
+    float n_pred;                        // batch x n_out
 };
 __global__ void adam_kernel(size_t n, float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float lr, float c1, float c2, const AdamTail t) {
@@ -374,6 +382,10 @@ __global__ void adam_kernel(size_t n, float* __restrict__ theta, float* __restri
     }
     if (i >= n) return;
     float gi = g[i];
+    if (i >= t.ob_out && i < t.ob_out + (size_t)t.n_out) {
+        gi = (float)t.sign_count[i - t.ob_out] / t.n_pred;
+        t.sign_count[i - t.ob_out] = 0;
+    }
     if (t.part_b) {
         for (int l = 0; l < t.L; ++l) {
             if (i >= t.ob[l] && i < t.ob[l] + (size_t)t.H) {
@@ -491,6 +503,7 @@ struct Policy {
     float *part = nullptr;     // partial column sums [2][RCHUNK][max(hidden, n_out)]
     float *part_b = nullptr;   // partial bias-gradient sums of the hidden layers [L][RCHUNK][hidden]
     float *loss_part = nullptr;   // per-block partial losses of l1_kernel
+    float *sign_count = nullptr;  // int[n_out]: l1_kernel's sign counts (allocated and zeroed with the float buffers)
     bool grad_dirty = false;   // a step that did not reach adam_kernel left grad non-zero
     long long step = 0;
     std::string err;
@@ -593,7 +606,8 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->act, (size_t)L * Bm * H}, {&p->z, (size_t)L * Bm * H}, {&p->dbuf[0], Bm * wide}, {&p->dbuf[1], Bm * wide},
         {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out},
         {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)},
-        {&p->part_b, (size_t)L * RCHUNK * H}, {&p->loss_part, (Bm * dims->n_out + 255) / 256 + 1}};
+        {&p->part_b, (size_t)L * RCHUNK * H}, {&p->loss_part, (Bm * dims->n_out + 255) / 256 + 1},
+        {&p->sign_count, (size_t)dims->n_out}};
     hipError_t e = hipSetDevice(device_id);
     for (auto& b : bufs) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b.ptr), b.n * sizeof(float));
@@ -614,7 +628,7 @@ void nmpc_policy_destroy(void* handle) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
-                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part};
+                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part, p->sign_count};
     for (float* q : all) if (q) (void)hipFree(q);
     delete p;
 }
@@ -687,13 +701,16 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     PTRY(p, hipSetDevice(p->device));
     const int L = p->d.n_hidden, H = p->d.hidden, no = p->d.n_out;
     const bool bn = p->d.batch_norm != 0;
-    if (p->grad_dirty) PTRY(p, hipMemsetAsync(p->grad, 0, p->n_theta * sizeof(float), st));   // normally left zero by adam_kernel
+    if (p->grad_dirty) {                                    // normally both are left zero by adam_kernel
+        PTRY(p, hipMemsetAsync(p->grad, 0, p->n_theta * sizeof(float), st));
+        PTRY(p, hipMemsetAsync(p->sign_count, 0, (size_t)no * sizeof(int), st));
+    }
     p->grad_dirty = true;
     forward(p, B, X, p->pred, true, st);
     if (pred) PTRY(p, hipMemcpyAsync(pred, p->pred, (size_t)B * no * sizeof(float), hipMemcpyDeviceToDevice, st));
     const size_t np_ = (size_t)B * no;
     hipLaunchKernelGGL(l1_kernel, dim3(blocks_for(np_)), dim3(256), 0, st, np_, no, p->pred, Y, p->dpred, p->loss_part,
-                       p->grad + p->ob[L]);
+                       reinterpret_cast<int*>(p->sign_count));
     // output layer: dW = dP' a_L, db = colsum dP, d = dP W
     const float* aL = p->act + (size_t)(L - 1) * p->d.batch_max * H;
     gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr, SPLIT_K);
@@ -728,6 +745,7 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     for (int l = 0; l < L; ++l) tail.ob[l] = p->ob[l];
     tail.L = L; tail.H = H;
     tail.loss_part = p->loss_part; tail.n_loss_part = (int)blocks_for(np_); tail.loss = loss;
+    tail.sign_count = reinterpret_cast<int*>(p->sign_count); tail.ob_out = p->ob[L]; tail.n_out = no; tail.n_pred = (float)np_;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(p->n_theta)), dim3(256), 0, st, p->n_theta, p->theta, p->grad,
                        p->m, p->v, lr, c1, c2, tail);
     p->grad_dirty = false;

@@ -124,3 +124,39 @@ def centroidal_trot(B: int = 1024, N: int = 50, seed: int = 0, warm: str = "stan
     return Workload(MODEL_CENTROIDAL, N, mp, W, cost.W_e_base.copy(), x0, yref, yref_e, params, X, U,
                     dict(config="2: centroidal trot", v_des=v_des, i_node=i_node,
                          reg=cost.reg_eps, reg_e=cost.reg_eps_e))
+
+
+def quadruped_tree(seed: int = 0, perturb: float = 0.0) -> Dict[str, np.ndarray]:
+    """A declared quadruped-shaped tree of 1-DoF joints for the torque layer (include/nmpc_torque.h) -- NOT the
+    reference's URDF, which is not in the image: three prismatic + three revolute virtual joints (yaw, pitch,
+    roll: the reference's state order, dynamics.py:146-148), a 6.9 kg trunk on the last of them, four legs
+    [FL, FR, RL, RR] of hip abduction (x), hip flexion (y), knee (y) with point feet.  perturb > 0 tilts axes and
+    placements randomly so that tests do not only see axis-aligned geometry.  Keys = BatchedTorqueLayer arguments."""
+    rng = np.random.default_rng(seed)
+    cols = {k: [] for k in ("parent", "joint_type", "axis", "placement_R", "placement_p", "mass", "com", "inertia")}
+
+    def rotation(axis, angle):
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+    def add(par, typ, ax, p, m_, c, i6):
+        ax = np.asarray(ax, float) + perturb * rng.standard_normal(3)
+        tilt = rng.standard_normal(3)
+        Rf = rotation(tilt / np.linalg.norm(tilt), perturb * rng.standard_normal()) if perturb else np.eye(3)
+        for k, val in zip(cols, (par, typ, ax / np.linalg.norm(ax), Rf, np.asarray(p, float), m_, np.asarray(c, float), np.asarray(i6, float))):
+            cols[k].append(val)
+        return len(cols["parent"]) - 1
+    j = -1
+    for typ, ax in ((1, (1, 0, 0)), (1, (0, 1, 0)), (1, (0, 0, 1)), (0, (0, 0, 1)), (0, (0, 1, 0))):
+        j = add(j, typ, ax, (0, 0, 0), 0.0, (0, 0, 0), (0, 0, 0, 0, 0, 0))
+    trunk = add(j, 0, (1, 0, 0), (0, 0, 0), 6.9, (0.02, 0.0, -0.005), (0.025, 1e-4, 2e-4, 0.098, 1e-5, 0.107))
+    foot_joint, foot_offset = [], []
+    for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)):
+        hip = add(trunk, 0, (1, 0, 0), (0.19 * sx, 0.047 * sy, 0.0), 0.68, (-0.005 * sx, 0.001 * sy, 0.0), (4.9e-4, 0, 0, 6.4e-4, 0, 5.7e-4))
+        thigh = add(hip, 0, (0, 1, 0), (0.0, 0.095 * sy, 0.0), 1.15, (-0.004, -0.016 * sy, -0.033), (5.8e-3, 0, 3e-4, 5.6e-3, 0, 1.0e-3))
+        calf = add(thigh, 0, (0, 1, 0), (0.0, 0.0, -0.213), 0.19, (0.006, 0.0, -0.13), (2.4e-3, 0, 0, 2.4e-3, 0, 4e-5))
+        foot_joint.append(calf); foot_offset.append((0.0, 0.0, -0.213))
+    out = {k: np.asarray(v) for k, v in cols.items()}
+    out.update(foot_joint=np.asarray(foot_joint), foot_offset=np.asarray(foot_offset, float), n_actuated=12,
+               gravity=np.array([0.0, 0.0, -9.81]))
+    return out

@@ -49,6 +49,12 @@ class TreeModel:
         self.n, self.nu, self.gravity = len(self.parent), int(n_actuated), np.asarray(gravity, float)
         assert all(p < i for i, p in enumerate(self.parent)), "parents come before children"
 
+    @classmethod
+    def from_arrays(cls, t):
+        """From the argument dictionary of the product's BatchedTorqueLayer (the tests hand both the same arrays)."""
+        return cls(t["parent"], t["joint_type"], t["axis"], t["placement_R"], t["placement_p"], t["mass"], t["com"], t["inertia"],
+                   t["foot_joint"], t["foot_offset"], t["n_actuated"], t.get("gravity", (0.0, 0.0, -9.81)))
+
     def joint_transform(self, i, qi):
         """(R, p): x_parent = R x_child + p."""
         if self.jtype[i] == 0:
@@ -166,31 +172,3 @@ def lagrangian_torques(m: TreeModel, q, v, a, f_world, h=1e-6):
             J[:, k] = (foot(q + e) - foot(q - e)) / (2 * h)
         tau -= J.T @ np.asarray(f_world[kf], float)
     return tau
-
-
-def quadruped_model(seed=0, perturb=0.0):
-    """A declared quadruped-shaped tree (NOT the reference's URDF, which is not in the image): three prismatic
-    + three revolute virtual joints (yaw, pitch, roll -- the reference's state order), a 6.9 kg trunk on the
-    last of them, four legs of hip-abduction (x), hip-flexion (y), knee (y) with point feet.  perturb > 0 tilts
-    axes and placements randomly so that tests do not only see axis-aligned geometry."""
-    rng = np.random.default_rng(seed)
-    parent, jtype, axis, R_fix, p_fix, mass, com, inertia = [], [], [], [], [], [], [], []
-
-    def add(par, typ, ax, p, m_, c, i6):
-        ax = np.asarray(ax, float) + perturb * rng.standard_normal(3)
-        tilt = rng.standard_normal(3)
-        Rf = _axis_rotation(tilt / np.linalg.norm(tilt), perturb * rng.standard_normal()) if perturb else np.eye(3)
-        parent.append(par); jtype.append(typ); axis.append(ax / np.linalg.norm(ax)); R_fix.append(Rf)
-        p_fix.append(np.asarray(p, float)); mass.append(m_); com.append(np.asarray(c, float)); inertia.append(np.asarray(i6, float))
-        return len(parent) - 1
-    j = -1
-    for typ, ax in ((1, (1, 0, 0)), (1, (0, 1, 0)), (1, (0, 0, 1)), (0, (0, 0, 1)), (0, (0, 1, 0))):
-        j = add(j, typ, ax, (0, 0, 0), 0.0, (0, 0, 0), (0, 0, 0, 0, 0, 0))
-    trunk = add(j, 0, (1, 0, 0), (0, 0, 0), 6.9, (0.02, 0.0, -0.005), (0.025, 1e-4, 2e-4, 0.098, 1e-5, 0.107))
-    foot_joint, foot_offset = [], []
-    for sx, sy in ((1, 1), (1, -1), (-1, 1), (-1, -1)):                       # FL, FR, RL, RR
-        hip = add(trunk, 0, (1, 0, 0), (0.19 * sx, 0.047 * sy, 0.0), 0.68, (-0.005 * sx, 0.001 * sy, 0.0), (4.9e-4, 0, 0, 6.4e-4, 0, 5.7e-4))
-        thigh = add(hip, 0, (0, 1, 0), (0.0, 0.095 * sy, 0.0), 1.15, (-0.004, -0.016 * sy, -0.033), (5.8e-3, 0, 3e-4, 5.6e-3, 0, 1.0e-3))
-        calf = add(thigh, 0, (0, 1, 0), (0.0, 0.0, -0.213), 0.19, (0.006, 0.0, -0.13), (2.4e-3, 0, 0, 2.4e-3, 0, 4e-5))
-        foot_joint.append(calf); foot_offset.append((0.0, 0.0, -0.213))
-    return TreeModel(parent, jtype, axis, R_fix, p_fix, mass, com, inertia, foot_joint, foot_offset, n_actuated=12)

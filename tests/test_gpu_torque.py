@@ -4,6 +4,8 @@ torque of a sample (sums of ~100 products of O(1..100) terms)."""
 import numpy as np
 import pytest
 
+from iterative_learning_nmpc_amd.workloads import quadruped_tree
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -11,6 +13,7 @@ CTRL_TO_JOINT = [3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8]          # ctrl [FR, FL, 
 
 
 def layer(m):
+    """The device layer for the arrays an oracle model holds."""
     from iterative_learning_nmpc_amd.torque import BatchedTorqueLayer
     return BatchedTorqueLayer(m.parent, m.jtype, m.axis, m.R_fix, m.p_fix, m.mass, m.com, m.inertia, m.foot_joint, m.foot_offset,
                               m.nu, gravity=m.gravity)
@@ -26,7 +29,7 @@ def batch(m, B, seed):
 @pytest.mark.parametrize("perturb,B", [(0.0, 1), (0.0, 257), (0.3, 64), (0.3, 1000)])
 def test_id_torques_match_oracle(perturb, B):
     from oracle import torque_oracle as to
-    m = to.quadruped_model(seed=4, perturb=perturb)
+    m = to.TreeModel.from_arrays(quadruped_tree(seed=4, perturb=perturb))
     q, v, a, f = batch(m, B, seed=B)
     tau = layer(m).id_torques(q, v, a, f).cpu().numpy()
     ref = to.id_torques_batch(m, *(x.astype(np.float64) for x in (q, v, a, f)))
@@ -59,7 +62,7 @@ def test_general_tree_with_prismatic_joints_and_every_joint_actuated():
 
 def test_pd_law_and_recorded_action_round_trip():
     from oracle import torque_oracle as to
-    m = to.quadruped_model()
+    m = to.TreeModel.from_arrays(quadruped_tree())
     L = layer(m)
     rng = np.random.default_rng(3)
     q, v, qp, vp = (rng.standard_normal((40, m.n)).astype(np.float32) for _ in range(4))
@@ -83,7 +86,7 @@ def test_model_errors():
     from iterative_learning_nmpc_amd._lib import NmpcError
     from iterative_learning_nmpc_amd.torque import BatchedTorqueLayer
     from oracle import torque_oracle as to
-    m = to.quadruped_model()
+    m = to.TreeModel.from_arrays(quadruped_tree())
     bad_parent = list(m.parent); bad_parent[3] = 7
     with pytest.raises(NmpcError, match="parents"):
         BatchedTorqueLayer(bad_parent, m.jtype, m.axis, m.R_fix, m.p_fix, m.mass, m.com, m.inertia, m.foot_joint, m.foot_offset, m.nu)

@@ -4,6 +4,8 @@ step with the recursion -- and against closed-form facts."""
 import numpy as np
 import pytest
 
+from iterative_learning_nmpc_amd.workloads import quadruped_tree
+
 from oracle import torque_oracle as to
 
 
@@ -15,7 +17,7 @@ def sample(m, rng, scale=1.0):
 
 @pytest.mark.parametrize("perturb", [0.0, 0.3])
 def test_newton_euler_equals_lagrange(perturb):
-    m = to.quadruped_model(seed=4, perturb=perturb)
+    m = to.TreeModel.from_arrays(quadruped_tree(seed=4, perturb=perturb))
     rng = np.random.default_rng(1)
     for _ in range(4):
         q, v, a, f = sample(m, rng)
@@ -26,7 +28,7 @@ def test_newton_euler_equals_lagrange(perturb):
 def test_static_stance_carries_the_weight():
     """Standing still on four feet that carry the weight equally: the virtual base joints need no force
     (sum of forces and moments balance up to the off-centre mass), and every term is gravity + J^T f."""
-    m = to.quadruped_model()
+    m = to.TreeModel.from_arrays(quadruped_tree())
     q = np.zeros(m.n); q[2] = 0.4
     q[6:] = np.tile([0.0, 0.7, -1.4], 4)
     weight = m.mass.sum() * 9.81
@@ -39,7 +41,7 @@ def test_static_stance_carries_the_weight():
 
 
 def test_torques_are_affine_in_acceleration_and_force():
-    m = to.quadruped_model(seed=2, perturb=0.2)
+    m = to.TreeModel.from_arrays(quadruped_tree(seed=2, perturb=0.2))
     rng = np.random.default_rng(3)
     q, v, a, f = sample(m, rng)
     t0 = to.id_torques(m, q, v, a, f)
