@@ -63,8 +63,10 @@ int nmpc_policy_train_step(void *handle, int B, const float *X, const float *Y, 
 int nmpc_weighted_sample(const float *weights, long long n, int num_samples, unsigned long long seed,
                          double *scratch, int *idx, void *stream);
 
-/* Batch assembly behind the sampler: dst[i][0..row_len) = src[idx[i]][0..row_len). */
-int nmpc_gather_rows(const float *src, int row_len, const int *idx, int n_idx, float *dst, void *stream);
+/* Batch assembly behind the sampler: dst[i][0..row_len) = src[idx[i]][0..row_len) for a table of n_rows
+ * rows; an idx outside [0, n_rows) is not read, its output row is NaN. */
+int nmpc_gather_rows(const float *src, long long n_rows, int row_len, const int *idx, int n_idx, float *dst,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,7 @@ SIGNATURES = {
     "nmpc_policy_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_policy_train_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "nmpc_weighted_sample": (c_int, [c_void_p, ctypes.c_longlong, c_int, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p]),
-    "nmpc_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "nmpc_gather_rows": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     # include/nmpc_dataset.h
     "nmpc_dataset_last_error": (ctypes.c_char_p, []),
     "nmpc_ring_append": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),

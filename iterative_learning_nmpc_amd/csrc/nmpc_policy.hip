@@ -471,12 +471,13 @@ __global__ void sample_kernel(const double* __restrict__ cdf, long long n, const
     idx[i] = (int)lo;
 }
 
-__global__ void gather_rows_kernel(const float* __restrict__ src, int row_len, const int* __restrict__ idx, int n_idx,
-                                   float* __restrict__ dst) {
+__global__ void gather_rows_kernel(const float* __restrict__ src, long long n_rows, int row_len, const int* __restrict__ idx,
+                                   int n_idx, float* __restrict__ dst) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)n_idx * row_len) return;
     const int i = (int)(e / row_len), j = (int)(e - (size_t)i * row_len);
-    dst[e] = src[(size_t)idx[i] * row_len + j];
+    const long long r = idx[i];                      // never read outside the table: a bad index shows up as NaN
+    dst[e] = (r >= 0 && r < n_rows) ? src[(size_t)r * row_len + j] : NAN;
 }
 
 }  // namespace nmpc_policy
@@ -772,13 +773,13 @@ int nmpc_weighted_sample(const float* weights, long long n, int num_samples, uns
     return NMPC_OK;
 }
 
-int nmpc_gather_rows(const float* src, int row_len, const int* idx, int n_idx, float* dst, void* stream) {
+int nmpc_gather_rows(const float* src, long long n_rows, int row_len, const int* idx, int n_idx, float* dst, void* stream) {
     if (n_idx == 0) return NMPC_OK;
     if (!src || !idx || !dst) return pfail(nullptr, NMPC_E_ARG, "null argument");
-    if (row_len < 1 || n_idx < 0) return pfail(nullptr, NMPC_E_ARG, "need row_len >= 1, n_idx >= 0");
+    if (row_len < 1 || n_idx < 0 || n_rows < 1) return pfail(nullptr, NMPC_E_ARG, "need n_rows, row_len >= 1, n_idx >= 0");
     const size_t n = (size_t)n_idx * row_len;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       src, row_len, idx, n_idx, dst);
+                       src, n_rows, row_len, idx, n_idx, dst);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pfail(nullptr, NMPC_E_HIP, hipGetErrorString(e));
     return NMPC_OK;

@@ -169,7 +169,7 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 2
     assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
     dst = torch.empty(idx.numel(), src.shape[1], dtype=torch.float32, device=src.device)
-    rc = lib.nmpc_gather_rows(_ptr(src), src.shape[1], _ptr(idx), idx.numel(), _ptr(dst), _stream(src.device))
+    rc = lib.nmpc_gather_rows(_ptr(src), src.shape[0], src.shape[1], _ptr(idx), idx.numel(), _ptr(dst), _stream(src.device))
     if rc:
         raise _lib.NmpcError(f"nmpc_gather_rows: {lib.nmpc_policy_last_error(None).decode()}")
     return dst

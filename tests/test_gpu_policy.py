@@ -147,6 +147,8 @@ def test_weighted_sampler_follows_tracking_error_weights_and_gathers_batches():
     table = S.reshape(B * T, ns).contiguous()
     batch = gather_rows(table, idx[:1024].contiguous())
     assert torch.equal(batch, table[idx[:1024].long()])
+    bad = gather_rows(table, torch.tensor([3, B * T, -1], dtype=torch.int32, device=dev))      # out of range: not read, NaN
+    assert torch.equal(bad[0], table[3]) and torch.isnan(bad[1:]).all()
     # arbitrary positive weights: statistical agreement (prefix sums differ in the last bits)
     w2 = torch.tensor(rng.random(3000).astype(np.float32) + 0.01, device=dev)
     i2 = weighted_sample(w2, 600000, seed=9).cpu().numpy()
