@@ -320,6 +320,12 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     wave_sync();
     // every thread of the block takes part in every column flush (idle threads carry a null tile)
     auto flush = [&](int which, int j, const float (&v)[16]) {
+#ifdef LIN_T_NOFLUSH   // timing build (tools/lin_timing.sh): no hand-over, the column only stays alive
+        float sacc = 0.0f;
+        for (int i = 0; i < 16; ++i) sacc += v[i];
+        if (sacc == 123.456f) stage_col[tid] = sacc;
+        return;
+#endif
         f32x4* mine = reinterpret_cast<f32x4*>(stage_col + tid * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) mine[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
@@ -329,7 +335,11 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
         for (int i = 0; i < 4; ++i) {
             const int s = (tid >> 2) + 16 * i;
             float* tile = tile_of[which][s];
+#ifdef LIN_T_NOSTORE   // timing build: hand-over without the column stores
+            if (tile != nullptr && quad < G::RQ && a.B < 0)
+#else
             if (tile != nullptr && quad < G::RQ)
+#endif
                 *reinterpret_cast<f32x4*>(tile + j * G::SA + 4 * quad) =
                     *reinterpret_cast<const f32x4*>(stage_col + s * 16 + 4 * quad);
         }
@@ -355,6 +365,9 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
             v[i] = (i < NX) ? xn[i < NX ? i : 0] - x_next[i < NX ? i : 0] : 0.0f;
         flush(0, NX, v);
     }
+#ifdef LIN_T_NOTAIL    // timing build: no gradients / constraint values / masks
+    if (a.B > 0) return;
+#endif
     if (!stage) return;
     float cst = 0.0f;
 #pragma unroll

@@ -1,6 +1,16 @@
 #!/usr/bin/env bash
-# Diagnostic (GPU box): duration of nmpc_linearize_kernel for timing builds of the library (wrong results,
-# one cost removed each): libnmpc_t_<VARIANT>.so built with -DLIN_T_<VARIANT>.
+# Diagnostic: duration of nmpc_linearize_kernel for timing builds of the library (wrong results, one cost
+# removed each: -DLIN_T_NOFLUSH / NOSTORE / NOTAIL in nmpc_solve.hip).
+#   tools/lin_timing.sh build     (anywhere: hipcc cross-compiles)  -> iterative_learning_nmpc_amd/libnmpc_t_<VARIANT>.so
+#   tools/lin_timing.sh           (GPU box) rocprofv3 averages per library; delete the variants afterwards
+if [ "${1:-}" = build ]; then
+  cd "$(dirname "$0")/../iterative_learning_nmpc_amd/csrc" || exit 1
+  for v in NOFLUSH NOSTORE NOTAIL; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wno-unused-function -DLIN_T_$v \
+          -o ../libnmpc_t_$v.so nmpc_api.hip nmpc_policy.hip nmpc_dataset.hip nmpc_torque.hip || exit 1
+  done
+  exit 0
+fi
 export TMPDIR=/tmp
 for lib in iterative_learning_nmpc_amd/libnmpc_hip.so iterative_learning_nmpc_amd/libnmpc_t_*.so; do
   tag=$(basename $lib .so)
