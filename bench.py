@@ -422,7 +422,7 @@ def main():
                        "global_batch": world * B, "horizon": N, "parallelism": f"dp{world} (independent problems, no collective)"},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 6 % of the solve call)", "kernel_ms": kernel_ms,
+                         "kernel": "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 5 % of the solve call)", "kernel_ms": kernel_ms,
                          "flops_per_solve": flops, "bytes_per_solve": nbytes,
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS},
             "failed_problems": bad,
