@@ -4,7 +4,8 @@
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${here}/../libnmpc_hip.so"
+# -amdgpu-mfma-vgpr-form: MFMA operands stay in VGPRs when a kernel also has AGPRs (nmpc_solve.hip, nmpc_qp_kernel)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-      -fno-gpu-rdc -Wall -Wno-unused-function \
+      -fno-gpu-rdc -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form \
       "$@" -o "${out}" "${here}/nmpc_api.hip" "${here}/nmpc_policy.hip" "${here}/nmpc_dataset.hip" "${here}/nmpc_torque.hip"
 echo "built ${out}"

@@ -420,8 +420,14 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // otherwise over the model's short list (common_variant) with the run-time fallback for the rest.
 // Two kernels rather than one loop with everything: measured, the mere presence of the other
 // variants in the kernel costs the common ones 2.5 % (code layout, register allocation).
+// Registers: the resident variant runs one wave per SIMD and is compiled for that (second launch-bound
+// = waves per SIMD), so the ~45 values that do not fit into 256 VGPRs spill into AGPRs -- one
+// v_accvgpr move each -- instead of scratch memory, whose reloads sat in the interior-point update behind a
+// vmcnt(0) each (measured: -6 % per solve call).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs
+// keep their VGPR operands (with AGPRs available the compiler otherwise moves the accumulators there and
+// copies them back and forth: slower).  The lean variant needs two waves per SIMD and has no AGPRs left.
 template <class M, bool LEAN, bool BF16B, bool ALLV>
-__global__ __launch_bounds__(64, 2) void nmpc_qp_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -6,7 +6,7 @@
 if [ "${1:-}" = build ]; then
   cd "$(dirname "$0")/../iterative_learning_nmpc_amd/csrc" || exit 1
   for v in NOFLUSH NOSTORE NOTAIL; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wno-unused-function -DLIN_T_$v \
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form -DLIN_T_$v \
           -o ../libnmpc_t_$v.so nmpc_api.hip nmpc_policy.hip nmpc_dataset.hip nmpc_torque.hip || exit 1
   done
   exit 0
