@@ -249,21 +249,27 @@ __device__ __forceinline__ bool ldl_eliminate(float (&col)[NU], unsigned coupled
     return ok;
 }
 
-// wave reductions (64 lanes)
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+// wave reductions (64 lanes), result in every lane.  Within a row of 16 lanes four DPP exchanges (xor 1,
+// xor 2 inside the quads, then the mirrored halves and the mirrored row) leave the row's result in all its
+// lanes; the four rows meet through v_readlane.  ~11 instructions and ~100 cycles of dependent latency; the
+// same butterfly on __shfl_xor is six ds_bpermute round trips through the LDS crossbar (~500 cycles), and
+// the interior-point update runs up to six reductions per sweep on its critical path.
+template <int CTRL>
+__device__ __forceinline__ float dpp_exchange(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+    v = op(v, dpp_exchange<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = op(v, dpp_exchange<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = op(v, dpp_exchange<0x141>(v));   // row_half_mirror
+    v = op(v, dpp_exchange<0x140>(v));   // row_mirror
+    const float r0 = bcast(v, 0), r1 = bcast(v, 16), r2 = bcast(v, 32), r3 = bcast(v, 48);
+    return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
 
 }  // namespace nmpc
