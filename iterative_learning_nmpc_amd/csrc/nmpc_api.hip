@@ -26,7 +26,7 @@ struct Handle {
     float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
     float* roll = nullptr;   // rollout problem tensors: x0 alias, yref, yref_e, params (B_max sized)
     int n_cu = 256;          // compute units of the device
-    int force_variant = 0;   // NMPC_QP_VARIANT: 0 choose by batch size, 1 resident, 2 lean (tests, tuning)
+    int force_variant = 0;   // NMPC_QP_VARIANT: 0 resident unless it does not fit the LDS, 1 resident, 2 lean (tests, tuning)
     int all_patterns = 0;    // nmpc_set_contact_patterns: 1 = kernel with a static stage body per contact pattern
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
@@ -74,8 +74,10 @@ size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
 
 // One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
-// Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays while every problem
-// of the batch gets a SIMD of its own, the lean layout (two waves per SIMD) beyond that.
+// Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays, one wave per SIMD, larger
+// batches in rounds -- the default at every batch size (measured: 2.13 M solves/s at B = 1024, 2.26 M at
+// 8192); the lean layout (stage arrays in the workspace, two waves per SIMD: 1.95 M at 8192) serves horizons
+// whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
 template <class M, bool LEAN, bool BF16B, bool ALLV>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
     const nmpc::Lds<M, LEAN> L(a.N);
@@ -102,7 +104,7 @@ int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
     const size_t resident_bytes = (size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float);
     const long long resident_waves = resident_bytes <= 160 * 1024 ? (long long)h->n_cu * (long long)((160 * 1024) / resident_bytes) : 0;
-    const bool lean = h->force_variant ? (h->force_variant > 1) : (a.B > resident_waves);
+    const bool lean = h->force_variant ? (h->force_variant > 1) : (resident_waves == 0);
     // all static variants only where the model has more than its short list and the caller asked for them
     if constexpr (M::N_STATIC_MASKS > 4) {
         if (h->all_patterns) {
