@@ -9,7 +9,7 @@ i=0
 for flags in "$@"; do
   i=$((i+1))
   lib="$here/gpurun_out/libnmpc_ab_$i.so"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -o "$lib" "$here/iterative_learning_nmpc_amd/csrc/nmpc_api.hip" 2>/dev/null || { echo "variant $i [$flags]: BUILD FAILED"; continue; }
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -mllvm -amdgpu-mfma-vgpr-form -o "$lib" "$here"/iterative_learning_nmpc_amd/csrc/nmpc_{api,policy,dataset,torque}.hip 2>/dev/null || { echo "variant $i [$flags]: BUILD FAILED"; continue; }
   for rep in 1 2; do
     NMPC_HIP_LIB="$lib" python3 "$here/bench.py" --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null | \
       python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('variant $i [$flags] rep $rep: kernel_ms %.4f  solves/s %.0f' % (d['roofline']['kernel_ms'], d['value']))"
