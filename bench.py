@@ -56,16 +56,24 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(w, n_ipm, sample):
+def cpu_baseline(w, n_ipm, sample, gpu_first=None):
     """The CPU oracle (fp64 restatement; the reference's acados solver is not installable here)
-    on all host cores, same workload, bounded sample."""
+    on all host cores, same workload, bounded sample.  gpu_first = (X, U) of the device's first solve of
+    the same inputs: the oracle, while it is at hand, also checks them (BASELINE's second metric, the
+    relative L2 error of the trajectories)."""
     from oracle.oracle import Oracle
     o = Oracle("f64")
     sl = slice(0, sample)
     args = (w.model_id, w.N, w.mp, o.opt(max_sqp_iter=1, n_ipm=n_ipm, yref_per_stage=1, reg=w.meta["reg"], reg_e=w.meta["reg_e"]),
             w.W, w.W_e, w.x0[sl], w.yref[sl], w.yref_e[sl], w.params[sl], w.X[sl], w.U[sl])
     threads = host_cores()
-    o.solve_batch(*args, nthreads=threads)     # warm (page in, thread pool)
+    Xo, Uo = o.solve_batch(*args, nthreads=threads)[:2]     # warm (page in, thread pool)
+    parity = None
+    if gpu_first is not None:
+        Xg, Ug = (np.asarray(v[sl], np.float64) for v in gpu_first)
+        parity = {"rel_l2_X": float(np.linalg.norm(Xg - Xo) / np.linalg.norm(Xo)),
+                  "rel_l2_U": float(np.linalg.norm(Ug - Uo) / np.linalg.norm(Uo)),
+                  "against": f"fp64 oracle, first solve of the {sample} problems (parity unpinned: DESIGN.md 2)"}
     reps, t0 = 0, time.perf_counter()
     while True:
         o.solve_batch(*args, nthreads=threads)
@@ -80,7 +88,7 @@ def cpu_baseline(w, n_ipm, sample):
     single = (time.perf_counter() - t1) / n1
     return dict(value=sample * reps / dt, unit="solves/s", cores=threads, kind="port",
                 sample=f"{sample} of the {w.B} problems x {reps} repeats, fp64 oracle (OpenMP over problems); "
-                       f"single-thread {single * 1e3:.2f} ms/solve")
+                       f"single-thread {single * 1e3:.2f} ms/solve", parity=parity)
 
 
 def rollout_mode(a, world, rank, dev, dist):
@@ -323,8 +331,8 @@ def torque_mode(a, world, rank, dev, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--ipm", type=int, default=6)
     ap.add_argument("--sqp", type=int, default=1)
@@ -375,6 +383,17 @@ def main():
     def step():       # warm-start shift by one node + solve, one call (nmpc_shift_solve_batch)
         s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats, shift=1)
 
+    # the first solve of the untouched inputs, kept for the parity figure of the cpu_baseline leg
+    s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats)
+    first = (t["X"].cpu().numpy().reshape(B, N + 1, -1), t["U"].cpu().numpy().reshape(B, N, -1))
+    t["X"].copy_(s.to_device(w.X)); t["U"].copy_(s.to_device(w.U))
+    # a fresh box starts at idle clocks: keep the device busy for a quarter of a second before the W warm-up
+    # steps, so that the K timed steps measure the steady state whatever W is (setup, not part of W or K)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.25:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -447,7 +466,7 @@ def main():
             "failed_problems": bad, "cold_start": cold,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, a.ipm, min(B, 1024))
+            out["cpu_baseline"] = cpu_baseline(w, a.ipm, min(B, 1024), first if (a.sqp == 1 and a.precision == 0) else None)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
