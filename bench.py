@@ -125,7 +125,7 @@ def rollout_mode(a, world, rank, dev, dist):
             times.append(time.perf_counter() - t0)
     el = float(np.mean(times))
     if dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     n_replans = S.shape[1]
@@ -168,7 +168,7 @@ def policy_mode(a, world, rank, dev, dist):
         dist.barrier()
     el = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms = e0.elapsed_time(e1) / a.steps
@@ -237,7 +237,7 @@ def database_mode(a, world, rank, dev, dist):
         dist.barrier()
     el = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms = e0.elapsed_time(e1) / a.steps
@@ -298,7 +298,7 @@ def torque_mode(a, world, rank, dev, dist):
         dist.barrier()
     el = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms = e0.elapsed_time(e1) / a.steps
@@ -357,8 +357,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # NMPC_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (the
+        # ranks then share the devices round robin and the timing reduction runs on CPU tensors); default RCCL
+        if os.environ.get("NMPC_BENCH_BACKEND", "nccl") == "gloo":
+            local = local % torch.cuda.device_count()
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -410,7 +416,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))

@@ -44,8 +44,14 @@ def all_gather_tracking_errors(err_local: torch.Tensor, total: int) -> torch.Ten
     send = err_local.contiguous()
     if send.shape[0] != n_max:
         send = torch.cat([send, send.new_zeros(n_max - send.shape[0], K)])
-    recv = send.new_empty(world * n_max, K)
-    dist.all_gather_into_tensor(recv, send)
+    if send.is_cuda and dist.get_backend() == "gloo":       # rehearsal on a box with fewer GPUs than ranks
+        host = send.cpu()
+        recv_h = host.new_empty(world * n_max, K)
+        dist.all_gather_into_tensor(recv_h, host)
+        recv = recv_h.to(send.device)
+    else:
+        recv = send.new_empty(world * n_max, K)
+        dist.all_gather_into_tensor(recv, send)
     if total == world * n_max:
         return recv
     parts = []
