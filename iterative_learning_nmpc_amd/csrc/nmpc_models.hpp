@@ -60,6 +60,8 @@ struct DoubleIntegrator {
     __host__ __device__ static constexpr int static_index(unsigned mask) { return mask == 0x3u ? 0 : -1; }
     // variants of the short dispatch list (see Centroidal); -1: unused entry
     __host__ __device__ static constexpr int common_variant(int i) { return i == 0 ? 0 : -1; }
+    // MFMA steps of the barrier product that can hold active rows under an input mask (all: the box rows)
+    __host__ __device__ static constexpr unsigned barrier_steps(unsigned) { return 0xFu; }
     __device__ static unsigned input_mask(const ModelParams&, const float*) { return 0x3u; }
 };
 
@@ -258,9 +260,13 @@ struct Centroidal {
         }
     }
 
-    // friction pyramid rows per foot f: +fx, -fx, +fy, -fy  minus mu fz  <= 0
+    // friction pyramid faces jj of foot f: +fx, -fx, +fy, -fy  minus mu fz  <= 0, as row 4 jj + f: in the
+    // 16-row tile of the barrier product lane quad q holds rows 4q..4q+3 and MFMA step i contracts register i
+    // of every quad -- with this order step i is "foot i, all four faces", so the steps of swing feet (all
+    // rows inactive: exact zeros) can be left out where the contact pattern is a compile-time constant
+    __host__ __device__ static constexpr int row_of(int f, int jj) { return 4 * jj + f; }
     __device__ static float G(const ModelParams& mp, int j, int c) {
-        const int f = j >> 2, jj = j & 3;
+        const int f = j & 3, jj = j >> 2;
         const int d = c - 3 * f;
         return (d == (jj >> 1)) ? ((jj & 1) ? -1.f : 1.f) : (d == 2 ? -mp.mu : 0.f);
     }
@@ -268,7 +274,7 @@ struct Centroidal {
     __device__ static unsigned active_mask(const ModelParams&, const float* p) {
         unsigned m = 0;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) m |= (p[f] > 0.5f) ? (0xFu << (4 * f)) : 0u;
+        for (int f = 0; f < 4; ++f) m |= (p[f] > 0.5f) ? (0x1111u << f) : 0u;
         return m;
     }
     // inputs that couple with others in Huu: the forces of stance feet.  A swing foot's force has a
@@ -293,6 +299,13 @@ struct Centroidal {
     // flight.  Other patterns take the run-time fallback there; gaits that show them select the kernel
     // with all sixteen variants (nmpc_set_contact_patterns).
     __host__ __device__ static constexpr int common_variant(int i) { return i == 0 ? 9 : i == 1 ? 6 : i == 2 ? 15 : i == 3 ? 0 : -1; }
+    // MFMA steps of the barrier product that can hold active rows under an input mask: step f = foot f
+    // (row_of), active iff the foot is in stance
+    __host__ __device__ static constexpr unsigned barrier_steps(unsigned mask) {
+        unsigned m = 0;
+        for (int f = 0; f < 4; ++f) m |= ((mask >> (3 * f)) & 1u) << f;
+        return m;
+    }
     // index of the static variant of a mask, -1 if there is none
     __host__ __device__ static constexpr int static_index(unsigned mask) {
         int i = 0;
@@ -303,10 +316,10 @@ struct Centroidal {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const float mz = mp.mu * v[3 * f + 2];
-            o[4 * f + 0] = v[3 * f] - mz;
-            o[4 * f + 1] = -v[3 * f] - mz;
-            o[4 * f + 2] = v[3 * f + 1] - mz;
-            o[4 * f + 3] = -v[3 * f + 1] - mz;
+            o[row_of(f, 0)] = v[3 * f] - mz;
+            o[row_of(f, 1)] = -v[3 * f] - mz;
+            o[row_of(f, 2)] = v[3 * f + 1] - mz;
+            o[row_of(f, 3)] = -v[3 * f + 1] - mz;
         }
     }
 };

@@ -551,7 +551,11 @@ __global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveAr
             // coupling mask of the stage, with the index of its static variant (+1; 0 = none) on top:
             // the stage loop then dispatches on one shift instead of recomputing the index every stage
             const unsigned um = reinterpret_cast<const unsigned*>(ws + wl.umk)[k];
-            umask[k] = um | ((unsigned)(M::static_index(um) + 1) << 16);
+            // bit 24: stage k-1 (the next one of the backward sweep, whose barrier product is built in this stage's
+            // body) has active constraint rows in MFMA steps that this stage's pattern does not have
+            const unsigned um_prev = reinterpret_cast<const unsigned*>(ws + wl.umk)[k > 0 ? k - 1 : 0];
+            const unsigned wider = (k > 0 && (M::barrier_steps(um_prev) & ~M::barrier_steps(um)) != 0u) ? 1u : 0u;
+            umask[k] = um | ((unsigned)(M::static_index(um) + 1) << 16) | (wider << 24);
             nact_l += __popc(am);
             mu_l += a.mu0 * (float)__popc(am);      // s * (mu0 / s) per active row
         }
@@ -751,9 +755,15 @@ __global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveAr
                     const unsigned cm_next = umask[kn + lane_zero];
                     f32x4 Kk, Acl;
                     NextCost sh = next_cost(kn);
+                    // a static body holds the barrier-product steps of its own stance feet only: exact zeros elsewhere
+                    // while the next stage's pattern is the same or narrower.  The rare stage before a touch-down
+                    // (bit 24 of the mask word) runs the body of the widest pattern instead -- valid for any pattern
+                    // (it eliminates every pivot for real), all four steps, and no extra code on the common path
                     auto run = [&](auto mask_tag) {
-                        return backward_stage<NU, decltype(mask_tag)::value, true, ALLV>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
-                                                                             cm & 0xFFFFu, Kk, Acl, sh SST_PASS);
+                        constexpr unsigned MK = decltype(mask_tag)::value;
+                        constexpr unsigned STEPS = (IPM && !BF16B && MK != DYNAMIC_MASK) ? M::barrier_steps(MK) : 0xFu;
+                        return backward_stage<NU, MK, true, ALLV, STEPS>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
+                                                                        cm & 0xFFFFu, Kk, Acl, sh SST_PASS);
                     };
                     bool ok = true;
                     // one static variant per mask: the model's short list as a chain (ALLV = false), or
@@ -766,7 +776,8 @@ __global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveAr
         break;
 #define NMPC_COMMON(J) (M::common_variant(J) >= 0 && vi == M::common_variant(J))
 #define NMPC_RUN_COMMON(J) run(std::integral_constant<unsigned, M::static_mask(M::common_variant(J) >= 0 ? M::common_variant(J) : 0)>{})
-                    const int vi = (int)(cm >> 16) - 1;
+                    constexpr int WIDEST = M::static_index((NU < 32) ? ((1u << NU) - 1u) : 0xFFFFFFFFu);
+                    const int vi = ((cm >> 24) & 1u) ? WIDEST : (int)((cm >> 16) & 0x1Fu) - 1;
                     if constexpr (!ALLV) {
                         if (NMPC_COMMON(0)) ok = NMPC_RUN_COMMON(0);
                         else if (NMPC_COMMON(1)) ok = NMPC_RUN_COMMON(1);

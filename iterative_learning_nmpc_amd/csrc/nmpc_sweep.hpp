@@ -94,7 +94,7 @@ __device__ __forceinline__ void xty_pair(f32x4 X0, f32x4 Y0, f32x4& C0, f32x4 X1
 // rows), so W and Y come back from the LDS with zero padding and need no masking.
 // Outputs (accumulator layout): K~ = -W'Y, Acl~ = A~ + B~K~  with  W = D^-1/2 L^-1,
 // Y = D^-1/2 L^-1 H~ux.  Returns false on a non-positive pivot.
-template <int NU, unsigned MASK, bool SLOT3, bool RSF_LDS, class NextCost>
+template <int NU, unsigned MASK, bool SLOT3, bool RSF_LDS, unsigned NEXT_STEPS = 0xFu, class NextCost>
 __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Bt, f32x4 Qt, f32x4 St,
                                                f32x4 Rt, float* conv, const SweepLane& sl, int lane,
                                                unsigned coupled, f32x4& Kout, f32x4& Aclout,
@@ -144,7 +144,8 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     for (int i = 0; i < NU; ++i) col[i] = SLOT3 ? cq[i / 3][i % 3] : cq[i >> 2][i & 3];
     nc.build();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nc.mfma(i);
+    for (int i = 0; i < 4; ++i)
+        if ((NEXT_STEPS >> i) & 1u) nc.mfma(i);      // steps whose rows are all inactive in the next stage add exact zeros
     float rsf[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) rsf[j] = FREE_ROWS ? rq[j >> 2][j & 3] : sl.rs_free_s[j];
