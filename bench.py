@@ -339,6 +339,7 @@ def main():
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
                     help="0: fp32 (headline); 1: bf16 barrier product, BASELINE configs[4] (a different config, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold-start", action="store_true", help="leave out the 15-iteration cold-start variant (profiling runs)")
     ap.add_argument("--rollouts", type=int, default=0,
                     help="extra mode (not the headline metric): B rollouts per GPU of 2 s (50 replans) fully "
                          "on the device, tracking error vs the nominal rollout, all-gather over the ranks")
@@ -425,7 +426,7 @@ def main():
     # the cold-start variant of the same workload -- the reference's first solve runs 15 SQP
     # iterations (mpc.py:464-473) from the standing initial guess; reported next to the headline, not as it
     cold = None
-    if a.sqp == 1 and a.precision == 0:
+    if a.sqp == 1 and a.precision == 0 and not a.no_cold_start:
         X0, U0 = t["X"].clone(), t["U"].clone()
         X0.copy_(s.to_device(w.X)); U0.copy_(s.to_device(w.U))
         s.set_max_iter(15)

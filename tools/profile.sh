@@ -9,7 +9,7 @@ shift || true
 out="gpurun_out/prof_${tag}"
 mkdir -p "$out"
 export TMPDIR=/tmp
-bench=(python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@")
+bench=(python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cold-start "$@")
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- "${bench[@]}" > "$out/kt.json" 2> "$out/kt.err"
 i=0
 for grp in \
