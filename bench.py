@@ -139,7 +139,13 @@ def rollout_mode(a, world, rank, dev, dist):
                                    "tracking error vs nominal + all-gather of [B,50] errors",
                        "solves_per_s": world * B * n_replans / el,
                        "ood_fraction": float(ood.float().mean().item()),
-                       "failed_rollouts": int(mpc.failed.sum().item())}}), flush=True)
+                       "failed_rollouts": int(mpc.failed.sum().item())},
+            # the solves dominate a rollout: same per-solve FLOP count as the headline (first replan: 15 SQP iterations)
+            "roofline": (lambda fl: {"bound": "mfma", "achieved": fl / el / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": fl / el / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+                                     "kernel": "nmpc_qp_kernel<Centroidal> inside nmpc_rollout_batch", "kernel_ms": None})(
+                algorithmic_work(12, 12, 16, 16, 50, 6)[0] * B * (n_replans + 14)),
+            "cpu_baseline": None}), flush=True)
 
 
 def policy_mode(a, world, rank, dev, dist):
