@@ -232,9 +232,10 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 
 // LDS layout of one problem.  Two variants of the QP kernel:
 //   resident (LEAN = false): stage arrays + sweep operands + conversion tiles, 39.6 KB at N = 50 ->
-//       4 waves per CU, one per SIMD: the fastest single wave, used while the batch fits that way;
-//   lean (LEAN = true): the stage arrays live in the workspace, 18.4 KB -> 8 waves per CU.  Two
-//       waves per SIMD fill each other's stalls and double the VALU issue rate.
+//       4 waves per CU, one per SIMD, larger batches in rounds: the default at every batch size;
+//   lean (LEAN = true): the stage arrays live in the workspace, 18.4 KB -> 8 waves per CU, two per SIMD.
+//       Slower since the resident kernel got the register budget of one wave per SIMD;
+//       kept for horizons whose resident layout does not fit the LDS and as NMPC_QP_VARIANT=lean.
 template <class M, bool LEAN>
 struct Lds {
     int arr, qv, rv, gsq, gvt, act, umk, conv, total;   // float offsets
