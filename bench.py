@@ -475,7 +475,10 @@ def main():
                          "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 5 % of the solve call)", "kernel_ms": kernel_ms,
                          "flops_per_solve": flops, "bytes_per_solve": nbytes,
-                         "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS},
+                         "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                         "binds": "dependent-issue latency of the serial stage recursion, one wave per SIMD (rocprofv3, "
+                                  "profiles/r01_solve_b1024.md: MFMA pipe busy 26 % of wave cycles, VALU 34 %, stalls 27 %); "
+                                  "neither HBM nor the MFMA peak"},
             "failed_problems": bad, "cold_start": cold,
         }
         if world == 1 and not a.no_cpu_baseline:
