@@ -288,7 +288,7 @@ def test_open_loop_rollouts_match_oracle_driven_loop(dev, oracle64):
 
 
 # ------------------------------------------------------------------------------- edge cases
-@pytest.mark.parametrize("model,B,N", [(1, 1, 50), (1, 3, 7), (1, 5, 70), (0, 2, 1), (0, 7, 100)])
+@pytest.mark.parametrize("model,B,N", [(1, 1, 50), (1, 3, 7), (1, 5, 70), (1, 2, 64), (1, 2, 65), (0, 2, 1), (0, 7, 100)])
 def test_odd_batches_and_horizons(dev, oracle64, model, B, N):
     """Ragged sizes: B = 1, odd B, N below / above the 64-lane stage loop, N = 1."""
     from iterative_learning_nmpc_amd import workloads as wl
