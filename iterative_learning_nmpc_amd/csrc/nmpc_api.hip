@@ -75,8 +75,8 @@ size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
 // One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
 // Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays, one wave per SIMD, larger
-// batches in rounds -- the default at every batch size (measured: 2.13 M solves/s at B = 1024, 2.26 M at
-// 8192); the lean layout (stage arrays in the workspace, two waves per SIMD: 1.95 M at 8192) serves horizons
+// batches in rounds -- the default at every batch size (measured: 2.18 M solves/s at B = 1024, 2.27 M at
+// 8192); the lean layout (stage arrays in the workspace, two waves per SIMD: 1.96 M at 8192) serves horizons
 // whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
 template <class M, bool LEAN, bool BF16B, bool ALLV>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
