@@ -3,6 +3,7 @@
 No files, no network: everything is drawn from numpy `default_rng(seed)`.
   config 1  double integrator  nx=4  nu=2  N=20  B=1     (plumbing)
   config 2  centroidal quadruped nx=12 nu=12 N=50 B=1024 (headline)
+  config 3  whole-body quadruped nx=42 nu=30 N=30 B=8192 (BASELINE configs[2])
 Weights are the reference's Go2 trot cost (mpc_controller/config/quadruped/mpc_cost.py:26-57),
 contact flags come from the trot gait table (contact_planner.py:121-134) at a random phase,
 base references from the velocity-tracking reference generator (mpc.py:210-272).
@@ -24,15 +25,22 @@ HIP_OFFSETS = np.array([[0.19, 0.14, 0.0], [0.19, -0.14, 0.0], [-0.19, 0.14, 0.0
 
 MODEL_DOUBLE_INTEGRATOR = 0
 MODEL_CENTROIDAL = 1
-MODEL_DIMS = {MODEL_DOUBLE_INTEGRATOR: dict(nx=4, nu=2, np=0, ng=4),
-              MODEL_CENTROIDAL: dict(nx=12, nu=12, np=16, ng=16)}
+MODEL_WHOLEBODY = 2
+MODEL_DIMS = {MODEL_DOUBLE_INTEGRATOR: dict(nx=4, nu=2, np=0, ng=4, ny=6, ny_e=4),
+              MODEL_CENTROIDAL: dict(nx=12, nu=12, np=16, ng=16, ny=24, ny_e=12),
+              MODEL_WHOLEBODY: dict(nx=42, nu=30, np=20, ng=16, ny=82, ny_e=58)}
 
 # model parameter vector (shared layout with include/nmpc.h: NMPC_MP_*)
-MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax")
+MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax",
+            "p_gain", "hipx", "hipy", "lhip", "l1", "l2", "res0", "res1")
+# declared penalty weights of the whole-body model's stance and momentum-consistency residuals
+W_CONTACT = 50.0
+W_CONSISTENCY = 100.0
 
 
 def model_params(**kw) -> np.ndarray:
-    d = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0)
+    d = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0,
+             p_gain=50.0, hipx=0.19, hipy=0.047, lhip=0.095, l1=0.213, l2=0.213, res0=0.0, res1=0.0)
     d.update(kw)
     return np.array([d[k] for k in MP_NAMES], dtype=np.float64)
 
@@ -123,6 +131,92 @@ def centroidal_trot(B: int = 1024, N: int = 50, seed: int = 0, warm: str = "stan
         U[:, :, 2::3] = fz_share
     return Workload(MODEL_CENTROIDAL, N, mp, W, cost.W_e_base.copy(), x0, yref, yref_e, params, X, U,
                     dict(config="2: centroidal trot", v_des=v_des, i_node=i_node,
+                         reg=cost.reg_eps, reg_e=cost.reg_eps_e))
+
+
+def wholebody_weights(cost, w_contact: float = W_CONTACT, w_consistency: float = W_CONSISTENCY):
+    """W[82], W_e[58] of the whole-body model in the residual order of include/nmpc.h: base, joint, acc, swing,
+    f_reg, contact, consistency / base, joint, swing, contact, consistency (solver.py:108-141)."""
+    W = np.concatenate([cost.W_base, cost.W_joint, cost.W_acc, cost.W_swing, np.asarray(cost.W_cnt_f_reg).ravel(),
+                        np.full(12, w_contact), np.full(6, w_consistency)])
+    W_e = np.concatenate([cost.W_e_base, cost.W_e_joint, cost.W_swing, np.full(12, w_contact),
+                          np.full(6, w_consistency)])
+    return W, W_e
+
+
+def anchor_plane_points(contacts: np.ndarray, feet_w: np.ndarray, height_offset: float = 0.0) -> np.ndarray:
+    """Per-node plane points of the four feet, [N+1, 4, 3]: (0, 0, height_offset) everywhere
+    (`init_contacts_parameters`, solver.py:212-225), then a foot that is in contact at node 0 keeps its current
+    position up to its next swing node (`setup_initial_feet_pos`, solver.py:194-210, including its `argmin`: a foot
+    in contact over the whole window is not anchored).  contacts: [4, N+1] flags, feet_w: [4, 3]."""
+    n1 = contacts.shape[1]
+    pp = np.zeros((n1, 4, 3))
+    pp[:, :, 2] = height_offset
+    for f in range(4):
+        if contacts[f, 0]:
+            next_swing = int(np.argmin(contacts[f]))
+            pp[:next_swing, f, :] = feet_w[f]
+    return pp
+
+
+def wholebody_trot(B: int = 8192, N: int = 30, seed: int = 0, sigma_joint: float = 0.2) -> Workload:
+    """BASELINE configs[2]: whole-body 18-DoF quadruped, nx = 42, nu = 30, trot, T = 1.0 s.
+
+    x0: base as config 2, joints q_home + N(0, sigma_joint) (DAgger/cfgs: sigma_joint_pos 0.2), joint rates
+    N(0, 0.2), momentum slots consistent with (q, v) as the reference's `pin_data.hg` (solver.py:187).  Warm start:
+    the state held, a = 0, every stance foot carrying an equal share of the weight."""
+    from . import wholebody as wb
+    rng = np.random.default_rng(seed)
+    gait, opt, cost = get_quadruped_config("trot", "go2")
+    T = opt.time_horizon
+    dt = T / N
+    mp = model_params(dt=dt)
+    planner = ContactPlanner(FEET, dt, gait)
+    d = MODEL_DIMS[MODEL_WHOLEBODY]
+
+    q0 = np.zeros((B, 18)); v0 = np.zeros((B, 18))
+    q0[:, 0:2] = rng.normal(0, 0.05, (B, 2))
+    q0[:, 2] = 0.30 + rng.normal(0, 0.02, B)
+    q0[:, 3:6] = rng.normal(0, 0.1, (B, 3))
+    q0[:, 6:] = wb.Q_HOME + rng.normal(0, sigma_joint, (B, 12))
+    v0[:, 0:3] = rng.normal(0, 0.2, (B, 3))
+    v0[:, 3:6] = rng.normal(0, 0.3, (B, 3))
+    v0[:, 6:] = rng.normal(0, 0.2, (B, 12))
+    v_des = np.stack([rng.uniform(0, 0.3, B), rng.uniform(-0.1, 0.1, B), np.zeros(B)], axis=1)
+    i_node = rng.integers(0, planner.nodes_per_cycle, B)
+    contacts = planner.get_contacts_batch(i_node, N + 1).astype(np.float64)      # [B,4,N+1]
+
+    inertia = mp[2:5]
+    x0 = np.zeros((B, d["nx"]))
+    params = np.zeros((B, N + 1, d["np"]))
+    yref = np.zeros((B, N, d["ny"]))
+    yref_e = np.zeros((B, d["ny_e"]))
+    for b in range(B):
+        x0[b, :18], x0[b, 18:36] = q0[b], v0[b]
+        x0[b, 36:] = wb.centroidal_momentum(q0[b], v0[b], mp[1], inertia)
+        params[b, :, 0:4] = contacts[b].T
+        params[b, :, 4:8] = 1.0 - contacts[b].T                                  # peak = 1 - contact (contact_planner.py:136-149)
+        params[b, :, 8:] = anchor_plane_points(contacts[b], wb.feet_position_w(q0[b])).reshape(N + 1, 12)
+        ref_state = np.zeros(12)
+        ref_state[:2] = q0[b, :2]
+        ref_state[3] = q0[b, 3]
+        base, base_e = base_ref_vel_tracking(q0[b], v_des[b], np.zeros(3), ref_state, T, gait.nom_height)
+        yref[b, :, 0:12] = base
+        yref_e[b, 0:12] = base_e
+    yref[:, :, 12:24] = wb.Q_HOME                  # joint reference = nominal pose, zero rates (solver.py:175-177)
+    yref[:, :, 48:52] = gait.step_height           # swing-height reference (solver.py:170)
+    yref_e[:, 12:24] = wb.Q_HOME
+    yref_e[:, 36:40] = gait.step_height
+    W, W_e = wholebody_weights(cost)
+    X = np.repeat(x0[:, None, :], N + 1, axis=1)
+    U = np.zeros((B, N, d["nu"]))
+    n_stance = np.maximum(contacts[:, :, :N].sum(1), 1.0)
+    U[:, :, 20::3] = np.moveaxis(contacts[:, :, :N], 1, 2) * ((-mp[5] * mp[1]) / n_stance)[:, :, None]
+    # force reference = gravity share of each stance foot [decl], as in config 2: with a zero reference the
+    # regularisation alone makes sagging cheaper than standing
+    yref[:, :, 52:64] = U[:, :, 18:30]
+    return Workload(MODEL_WHOLEBODY, N, mp, W, W_e, x0, yref, yref_e, params, X, U,
+                    dict(config="3: whole-body trot", v_des=v_des, i_node=i_node,
                          reg=cost.reg_eps, reg_e=cost.reg_eps_e))
 
 

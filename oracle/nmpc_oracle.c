@@ -71,6 +71,32 @@
  *           R = Rz(yaw) Ry(pitch) Rx(roll)  (pin.rpy.rpyToMatrix, mpc.py:205)
  *           friction pyramid per stance foot, mu = 0.8 (solver.py:38):
  *             +-fx - mu fz <= 0, +-fy - mu fz <= 0   (ng = 16; rows of swing feet inactive)
+ *  model 2  whole-body kinodynamic quadruped (BASELINE configs[2]), nx=42, nu=30.
+ *           Layouts are the reference's (solver.py:88-92,185-187,405-418):
+ *             x = [q(18) = r(3), (yaw,pitch,roll), joints(12) | v(18) = qdot | h(6) centroidal momentum]
+ *             u = [a(18) = vdot | f[4][3] world forces, feet FL,FR,RL,RR]
+ *           (the reference's velocity slots 3..5 are the Euler-angle rates, dynamics.py:69, so qdot = v).
+ *           p = [c(4) active, peak(4), plane_point(4x3)]  (solver.py:212-252; plane normal = e_z, :216)
+ *           The symbolic model itself lives in the absent contact_tamp; DECLARED here:
+ *           semi-implicit Euler, dt = T/N:  v+ = v + dt a,  q+ = q + dt v+,
+ *             h_lin+ = h_lin + dt (sum c_i f_i + m g),  h_ang+ = h_ang + dt sum c_i (p_i(q) - r) x f_i
+ *           legs: hip abduction (x) at (+-hipx, +-hipy, 0), thigh (y) at (0, +-lhip, 0), knee (y) at
+ *           (0,0,-l1), point foot at (0,0,-l2) -- the declared tree of workloads.quadruped_tree();
+ *           single-rigid-body inertia for the momentum map: A_g(q) v = [m rdot; R I_b E(th) thdot],
+ *           E = euler_derivative_to_local_angular (transform.py:80-86), COM at the base origin.
+ *           Gauss-Newton least-squares cost, residuals and weights in this order (ny = 82):
+ *             base(12)   [q[0:6], v[0:6]] - base_ref          W_base      dynamics.py:121-124
+ *             joint(24)  [q[6:], v[6:]] - [joint_ref, 0]      W_joint     dynamics.py:126, solver.py:175-177
+ *             acc(12)    a[6:]                                W_acc       dynamics.py:129
+ *             swing(4)   peak_i z_foot_i(q) - step_height     W_swing     dynamics.py:131-134, solver.py:170
+ *             f_reg(12)  f                                    W_cnt_f_reg solver.py:128-130
+ *             contact(12) c_i (J_i(q) v + p_gain e_z (z_foot_i - plane_point_i,z))   [decl weight]
+ *                        Baumgarte-stabilised stance constraint, p_gain = W_foot_pos_constr_stab = 50
+ *                        (solver.py:219, mpc_cost.py:60), entering as a quadratic penalty: the
+ *                        Riccati/IPM core of this build carries input inequalities only
+ *             consist(6) h - A_g(q) v                                               [decl weight]
+ *           terminal (ny_e = 58): base (W_e_base), joint (W_e_joint), swing, contact, consist.
+ *           friction pyramid on f as in model 1 (ng = 16).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -92,10 +118,12 @@ typedef double real;
 #define FABS fabs
 #endif
 
-#define MAXN 16 /* max nx, nu, ng handled by the oracle's stack buffers */
+#define MAXN 48 /* max nx, nu, ng handled by the oracle's stack buffers */
 
-/* model parameter vector mp[8]: dt, mass, Ixx, Iyy, Izz, gz, mu, umax */
-enum { MP_DT = 0, MP_MASS, MP_IXX, MP_IYY, MP_IZZ, MP_GZ, MP_MU, MP_UMAX, MP_COUNT };
+/* model parameter vector mp[16]: dt, mass, Ixx, Iyy, Izz, gz, mu, umax, then (model 2) p_gain and the leg
+ * geometry hipx, hipy, lhip, l1, l2; two reserved */
+enum { MP_DT = 0, MP_MASS, MP_IXX, MP_IYY, MP_IZZ, MP_GZ, MP_MU, MP_UMAX,
+       MP_PGAIN, MP_HIPX, MP_HIPY, MP_LHIP, MP_L1, MP_L2, MP_RES0, MP_RES1, MP_COUNT };
 /* option vector opt[13] */
 enum {
     OP_MAX_SQP = 0, OP_N_IPM, OP_NLP_TOL, OP_REG, OP_REG_E, OP_MU0, OP_SIGMA, OP_SMIN,
@@ -107,7 +135,17 @@ int oracle_real_size(void) { return (int)sizeof(real); }
 int oracle_dims(int model_id, int *nx, int *nu, int *np, int *ng) {
     if (model_id == 0) { *nx = 4; *nu = 2; *np = 0; *ng = 4; return 0; }
     if (model_id == 1) { *nx = 12; *nu = 12; *np = 16; *ng = 16; return 0; }
+    if (model_id == 2) { *nx = 42; *nu = 30; *np = 20; *ng = 16; return 0; }
     return -1;
+}
+
+/* number of cost residuals of a stage / of the terminal node (= length of W, yref / W_e, yref_e) */
+int oracle_output_dims(int model_id, int *ny, int *nye) {
+    int nx, nu, np, ng;
+    if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
+    if (model_id == 2) { *ny = 82; *nye = 58; return 0; }
+    *ny = nx + nu; *nye = nx;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ 3x3 helpers */
@@ -310,12 +348,314 @@ static void dyn_centroidal(const real *mp, const real *x, const real *u, const r
     }
 }
 
+/* ------------------------------------------------------------------ model 2 (whole body) */
+enum { WB_NX = 42, WB_NU = 30, WB_NP = 20, WB_NG = 16, WB_NY = 82, WB_NYE = 58 };
+enum { WQ = 0, WV = 18, WH = 36, WA = 0, WF = 18 };                    /* state / input offsets */
+enum { RY_BASE = 0, RY_JOINT = 12, RY_ACC = 36, RY_SWING = 48, RY_FREG = 52, RY_CNT = 64, RY_CONS = 76 };
+enum { RE_BASE = 0, RE_JOINT = 12, RE_SWING = 36, RE_CNT = 40, RE_CONS = 52 };
+
+static void m3_vec(const real *a, const real *v, real *o) { /* o = a v */
+    for (int i = 0; i < 3; i++) o[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
+}
+static void m3_acc3(const real *a, const real *b, const real *c, real s, real *o) { /* o += s a b c */
+    real t[9], u[9];
+    m3_mul(a, b, t);
+    m3_mul(t, c, u);
+    for (int i = 0; i < 9; i++) o[i] += s * u[i];
+}
+static void rot_axis(int axis, real ang, real *M, real *M1, real *M2) { /* R, dR/dang, d2R/dang2 */
+    const real c = COS(ang), s = SIN(ang);
+    for (int i = 0; i < 9; i++) M[i] = M1[i] = M2[i] = 0;
+    const int i0 = (axis + 1) % 3, i1 = (axis + 2) % 3;              /* the rotated plane */
+    M[4 * axis] = 1;
+    M[3 * i0 + i0] = c;  M[3 * i0 + i1] = -s; M[3 * i1 + i0] = s;  M[3 * i1 + i1] = c;
+    M1[3 * i0 + i0] = -s; M1[3 * i0 + i1] = -c; M1[3 * i1 + i0] = c;  M1[3 * i1 + i1] = -s;
+    M2[3 * i0 + i0] = -c; M2[3 * i0 + i1] = s;  M2[3 * i1 + i0] = -s; M2[3 * i1 + i1] = -c;
+}
+
+/* Kinematics of the four point feet at (q, v = qdot):  world position p_i, its Jacobian J_i (3x9) with respect to
+ * xi_i = [r, theta, ql_i] and the time derivative Jd_i of that Jacobian along v.  Since
+ *   d/dxi_c ( J(xi) xidot ) = sum_a d2p/dxi_a dxi_c xidot_a = d/dt ( dp/dxi_c ),
+ * Jd_i is also the Jacobian of the foot velocity with respect to the configuration. */
+typedef struct {
+    real R[9], Ra[3][9], Rd[9], Rad[3][9];
+    real b[4][3], Jb[4][9];
+    real p[4][3], J[4][27], Jd[4][27];
+} wb_kin_t;
+
+static void wb_kinematics(const real *mp, const real *x, int with_rates, wb_kin_t *k) {
+    real M[3][9], M1[3][9], M2[3][9], Md[3][9], M1d[3][9];
+    static const int axis_of[3] = {2, 1, 0};                          /* yaw: z, pitch: y, roll: x */
+    static const real zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < 3; a++) {
+        rot_axis(axis_of[a], x[WQ + 3 + a], M[a], M1[a], M2[a]);
+        const real rate = with_rates ? x[WV + 3 + a] : 0;
+        for (int i = 0; i < 9; i++) { Md[a][i] = M1[a][i] * rate; M1d[a][i] = M2[a][i] * rate; }
+    }
+    memcpy(k->R, zero9, sizeof zero9);
+    m3_acc3(M[0], M[1], M[2], 1, k->R);
+    memcpy(k->Rd, zero9, sizeof zero9);
+    m3_acc3(Md[0], M[1], M[2], 1, k->Rd);
+    m3_acc3(M[0], Md[1], M[2], 1, k->Rd);
+    m3_acc3(M[0], M[1], Md[2], 1, k->Rd);
+    for (int a = 0; a < 3; a++) {
+        const real *F[3] = {M[0], M[1], M[2]}, *Fd[3] = {Md[0], Md[1], Md[2]};
+        F[a] = M1[a];
+        Fd[a] = M1d[a];
+        memcpy(k->Ra[a], zero9, sizeof zero9);
+        m3_acc3(F[0], F[1], F[2], 1, k->Ra[a]);
+        memcpy(k->Rad[a], zero9, sizeof zero9);
+        m3_acc3(Fd[0], F[1], F[2], 1, k->Rad[a]);
+        m3_acc3(F[0], Fd[1], F[2], 1, k->Rad[a]);
+        m3_acc3(F[0], F[1], Fd[2], 1, k->Rad[a]);
+    }
+    static const real sgx[4] = {1, 1, -1, -1}, sgy[4] = {1, -1, 1, -1};
+    const real l1 = mp[MP_L1], l2 = mp[MP_L2];
+    for (int f = 0; f < 4; f++) {
+        const real *ql = x + WQ + 6 + 3 * f, *wl = x + WV + 6 + 3 * f;
+        const real d = sgy[f] * mp[MP_LHIP];
+        const real s1 = SIN(ql[0]), c1 = COS(ql[0]), s2 = SIN(ql[1]), c2 = COS(ql[1]);
+        const real s23 = SIN(ql[1] + ql[2]), c23 = COS(ql[1] + ql[2]);
+        const real vx = -l1 * s2 - l2 * s23, vz = -l1 * c2 - l2 * c23, vx3 = -l2 * s23, vz3 = -l2 * c23;
+        real *b = k->b[f], *Jb = k->Jb[f];
+        b[0] = sgx[f] * mp[MP_HIPX] + vx;
+        b[1] = sgy[f] * mp[MP_HIPY] + d * c1 - vz * s1;
+        b[2] = d * s1 + vz * c1;
+        Jb[0] = 0;                 Jb[1] = vz;       Jb[2] = vz3;
+        Jb[3] = -d * s1 - vz * c1; Jb[4] = vx * s1;  Jb[5] = vx3 * s1;
+        Jb[6] = d * c1 - vz * s1;  Jb[7] = -vx * c1; Jb[8] = -vx3 * c1;
+        real Jbd[9], bd[3];
+        {
+            const real w1 = with_rates ? wl[0] : 0, w2 = with_rates ? wl[1] : 0, w3 = with_rates ? wl[2] : 0;
+            const real w23 = w2 + w3;
+            const real s1d = c1 * w1, c1d = -s1 * w1;
+            const real vxd = vz * w2 + vz3 * w3, vzd = -vx * w2 - vx3 * w3;
+            const real vx3d = vz3 * w23, vz3d = -vx3 * w23;
+            Jbd[0] = 0;                                 Jbd[1] = vzd;                   Jbd[2] = vz3d;
+            Jbd[3] = -d * s1d - vzd * c1 - vz * c1d;    Jbd[4] = vxd * s1 + vx * s1d;   Jbd[5] = vx3d * s1 + vx3 * s1d;
+            Jbd[6] = d * c1d - vzd * s1 - vz * s1d;     Jbd[7] = -vxd * c1 - vx * c1d;  Jbd[8] = -vx3d * c1 - vx3 * c1d;
+            const real wv[3] = {w1, w2, w3};
+            m3_vec(Jb, wv, bd);
+        }
+        real Rb[3];
+        m3_vec(k->R, b, Rb);
+        for (int i = 0; i < 3; i++) k->p[f][i] = x[WQ + i] + Rb[i];
+        real *J = k->J[f], *Jd = k->Jd[f];
+        for (int i = 0; i < 27; i++) J[i] = Jd[i] = 0;
+        for (int i = 0; i < 3; i++) J[9 * i + i] = 1;
+        for (int a = 0; a < 3; a++) {
+            real t0[3], t1[3], t2[3];
+            m3_vec(k->Ra[a], b, t0);
+            m3_vec(k->Rad[a], b, t1);
+            m3_vec(k->Ra[a], bd, t2);
+            for (int i = 0; i < 3; i++) { J[9 * i + 3 + a] = t0[i]; Jd[9 * i + 3 + a] = t1[i] + t2[i]; }
+        }
+        for (int c = 0; c < 3; c++) {
+            const real jc[3] = {Jb[c], Jb[3 + c], Jb[6 + c]}, jdc[3] = {Jbd[c], Jbd[3 + c], Jbd[6 + c]};
+            real t0[3], t1[3], t2[3];
+            m3_vec(k->R, jc, t0);
+            m3_vec(k->Rd, jc, t1);
+            m3_vec(k->R, jdc, t2);
+            for (int i = 0; i < 3; i++) { J[9 * i + 6 + c] = t0[i]; Jd[9 * i + 6 + c] = t1[i] + t2[i]; }
+        }
+    }
+}
+/* column of x (or of v, +WV) that slot c of xi_f = [r, theta, ql_f] stands for */
+static int wb_xi(int f, int c) { return c < 6 ? c : 6 + 3 * f + (c - 6); }
+
+static void dyn_wholebody(const real *mp, const real *x, const real *u, const real *p, real *xn, real *A, real *B) {
+    const int nx = WB_NX, nu = WB_NU;
+    const real dt = mp[MP_DT];
+    wb_kin_t k;
+    wb_kinematics(mp, x, 0, &k);
+    for (int i = 0; i < 18; i++) {
+        const real vn = x[WV + i] + dt * u[WA + i];
+        xn[WV + i] = vn;
+        xn[WQ + i] = x[WQ + i] + dt * vn;
+    }
+    real F[3] = {0, 0, 0}, tau[3] = {0, 0, 0}, arm[4][3];
+    for (int f = 0; f < 4; f++) {
+        const real c = p[f];
+        const real *ff = u + WF + 3 * f;
+        real t[3];
+        m3_vec(k.R, k.b[f], arm[f]);
+        cross3(arm[f], ff, t);
+        for (int j = 0; j < 3; j++) { F[j] += c * ff[j]; tau[j] += c * t[j]; }
+    }
+    for (int j = 0; j < 3; j++) {
+        xn[WH + j] = x[WH + j] + dt * (F[j] + (j == 2 ? mp[MP_MASS] * mp[MP_GZ] : 0));
+        xn[WH + 3 + j] = x[WH + 3 + j] + dt * tau[j];
+    }
+    if (!A) return;
+    memset(A, 0, sizeof(real) * nx * nx);
+    memset(B, 0, sizeof(real) * nx * nu);
+    for (int i = 0; i < nx; i++) A[i * nx + i] = 1;
+    for (int i = 0; i < 18; i++) {
+        A[(WQ + i) * nx + WV + i] = dt;
+        B[(WQ + i) * nu + WA + i] = dt * dt;
+        B[(WV + i) * nu + WA + i] = dt;
+    }
+    for (int f = 0; f < 4; f++) {
+        const real c = p[f];
+        const real *ff = u + WF + 3 * f;
+        for (int j = 0; j < 3; j++) B[(WH + j) * nu + WF + 3 * f + j] = dt * c;
+        /* d(arm x f)/df = [arm]x */
+        const real ax[9] = {0, -arm[f][2], arm[f][1], arm[f][2], 0, -arm[f][0], -arm[f][1], arm[f][0], 0};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) B[(WH + 3 + i) * nu + WF + 3 * f + j] = dt * c * ax[3 * i + j];
+        /* d(arm x f)/dxi_c = (d arm/dxi_c) x f ; arm = R b does not depend on r */
+        for (int cc = 3; cc < 9; cc++) {
+            const real da[3] = {k.J[f][cc], k.J[f][9 + cc], k.J[f][18 + cc]};
+            real t[3];
+            cross3(da, ff, t);
+            for (int i = 0; i < 3; i++) A[(WH + 3 + i) * nx + WQ + wb_xi(f, cc)] += dt * c * t[i];
+        }
+    }
+}
+
+/* Residuals of the least-squares cost at (x, u, p), u == NULL: terminal node.  res[ny] (reference already
+ * subtracted), and, if Jx != NULL, the Jacobian with respect to x, dense [ny][nx].  The Jacobian with respect to
+ * u is a selection: rows RY_ACC + i -> u[6 + i], rows RY_FREG + i -> u[18 + i]. */
+static void wb_residuals(const real *mp, const real *x, const real *u, const real *p, const real *yref, real *res,
+                         real *Jx) {
+    const int nx = WB_NX, term = (u == NULL);
+    const int ny = term ? WB_NYE : WB_NY;
+    const int r_sw = term ? RE_SWING : RY_SWING, r_ct = term ? RE_CNT : RY_CNT, r_cs = term ? RE_CONS : RY_CONS;
+    wb_kin_t k;
+    wb_kinematics(mp, x, 1, &k);
+    if (Jx) memset(Jx, 0, sizeof(real) * ny * nx);
+    for (int i = 0; i < 6; i++) {
+        res[RY_BASE + i] = x[WQ + i];
+        res[RY_BASE + 6 + i] = x[WV + i];
+        if (Jx) { Jx[(RY_BASE + i) * nx + WQ + i] = 1; Jx[(RY_BASE + 6 + i) * nx + WV + i] = 1; }
+    }
+    for (int i = 0; i < 12; i++) {
+        res[RY_JOINT + i] = x[WQ + 6 + i];
+        res[RY_JOINT + 12 + i] = x[WV + 6 + i];
+        if (Jx) { Jx[(RY_JOINT + i) * nx + WQ + 6 + i] = 1; Jx[(RY_JOINT + 12 + i) * nx + WV + 6 + i] = 1; }
+    }
+    if (!term) {
+        for (int i = 0; i < 12; i++) { res[RY_ACC + i] = u[WA + 6 + i]; res[RY_FREG + i] = u[WF + i]; }
+    }
+    const real pg = mp[MP_PGAIN];
+    for (int f = 0; f < 4; f++) {
+        const real c = p[f], peak = p[4 + f], ppz = p[8 + 3 * f + 2];
+        res[r_sw + f] = peak * k.p[f][2];
+        real vel[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++)
+            for (int cc = 0; cc < 9; cc++) vel[i] += k.J[f][9 * i + cc] * x[WV + wb_xi(f, cc)];
+        for (int i = 0; i < 3; i++) res[r_ct + 3 * f + i] = c * (vel[i] + (i == 2 ? pg * (k.p[f][2] - ppz) : 0));
+        if (Jx)
+            for (int cc = 0; cc < 9; cc++) {
+                const int col = wb_xi(f, cc);
+                Jx[(r_sw + f) * nx + WQ + col] = peak * k.J[f][18 + cc];
+                for (int i = 0; i < 3; i++) {
+                    Jx[(r_ct + 3 * f + i) * nx + WQ + col] = c * (k.Jd[f][9 * i + cc] + (i == 2 ? pg * k.J[f][18 + cc] : 0));
+                    Jx[(r_ct + 3 * f + i) * nx + WV + col] = c * k.J[f][9 * i + cc];
+                }
+            }
+    }
+    {   /* consistency  h - A_g(q) v,  A_g v = [m rdot ; R I_b E(theta) thetadot] */
+        const real *th = x + WQ + 3, *thd = x + WV + 3;
+        const real Ib[3] = {mp[MP_IXX], mp[MP_IYY], mp[MP_IZZ]};
+        const real sy = SIN(th[1]), cy = COS(th[1]), sx = SIN(th[2]), cx = COS(th[2]);
+        const real E[9] = {-sy, 0, 1, cy * sx, cx, 0, cx * cy, -sx, 0};
+        const real Ea[3][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0},
+                               {-cy, 0, 0, -sy * sx, 0, 0, -cx * sy, 0, 0},
+                               {0, 0, 0, cy * cx, -sx, 0, -sx * cy, -cx, 0}};
+        real wb[3], Iw[3], L[3];
+        m3_vec(E, thd, wb);
+        for (int i = 0; i < 3; i++) Iw[i] = Ib[i] * wb[i];
+        m3_vec(k.R, Iw, L);
+        for (int i = 0; i < 3; i++) {
+            res[r_cs + i] = x[WH + i] - mp[MP_MASS] * x[WV + i];
+            res[r_cs + 3 + i] = x[WH + 3 + i] - L[i];
+        }
+        if (Jx) {
+            for (int i = 0; i < 3; i++) {
+                Jx[(r_cs + i) * nx + WH + i] = 1;
+                Jx[(r_cs + i) * nx + WV + i] = -mp[MP_MASS];
+                Jx[(r_cs + 3 + i) * nx + WH + 3 + i] = 1;
+            }
+            for (int a = 0; a < 3; a++) {
+                real t0[3], t1[3], ew[3], iew[3], ecol[3], iecol[3], t2[3];
+                m3_vec(k.Ra[a], Iw, t0);
+                m3_vec(Ea[a], thd, ew);
+                for (int i = 0; i < 3; i++) iew[i] = Ib[i] * ew[i];
+                m3_vec(k.R, iew, t1);
+                for (int i = 0; i < 3; i++) { ecol[i] = E[3 * i + a]; iecol[i] = Ib[i] * ecol[i]; }
+                m3_vec(k.R, iecol, t2);
+                for (int i = 0; i < 3; i++) {
+                    Jx[(r_cs + 3 + i) * nx + WQ + 3 + a] = -(t0[i] + t1[i]);
+                    Jx[(r_cs + 3 + i) * nx + WV + 3 + a] = -t2[i];
+                }
+            }
+        }
+    }
+    for (int i = 0; i < ny; i++) res[i] -= yref[i];
+}
+
+/* Gauss-Newton terms of one node: returns the cost 1/2 sum W res^2; if Q != NULL also
+ *   Q = Jx' W Jx + reg I  [nx][nx],  q = Jx' W res,  and for a stage  Rd = diag(Ju' W Ju) + reg  [nu],  r = Ju' W res. */
+static real wb_node_terms(const real *mp, const real *W, real reg, const real *x, const real *u, const real *p,
+                          const real *yref, real *Q, real *q, real *Rd, real *r) {
+    const int nx = WB_NX, nu = WB_NU, term = (u == NULL);
+    const int ny = term ? WB_NYE : WB_NY;
+    real res[WB_NY];
+    real *Jx = Q ? (real *)malloc(sizeof(real) * ny * nx) : NULL;
+    wb_residuals(mp, x, u, p, yref, res, Jx);
+    real cost = 0;
+    for (int i = 0; i < ny; i++) cost += (real)0.5 * W[i] * res[i] * res[i];
+    if (Q) {
+        for (int a = 0; a < nx; a++) {
+            real g = 0;
+            for (int i = 0; i < ny; i++) g += Jx[i * nx + a] * W[i] * res[i];
+            q[a] = g;
+            for (int b = 0; b < nx; b++) {
+                real s = (a == b) ? reg : 0;
+                for (int i = 0; i < ny; i++) s += Jx[i * nx + a] * W[i] * Jx[i * nx + b];
+                Q[a * nx + b] = s;
+            }
+        }
+        if (!term) {
+            for (int i = 0; i < nu; i++) { Rd[i] = reg; r[i] = 0; }
+            for (int i = 0; i < 12; i++) {
+                Rd[WA + 6 + i] += W[RY_ACC + i];
+                r[WA + 6 + i] = W[RY_ACC + i] * res[RY_ACC + i];
+                Rd[WF + i] += W[RY_FREG + i];
+                r[WF + i] = W[RY_FREG + i] * res[RY_FREG + i];
+            }
+        }
+        free(Jx);
+    }
+    return cost;
+}
+
+/* test hooks: residuals and their state Jacobian (terminal: u == NULL) */
+void oracle_wb_residuals(const real *mp, const real *x, const real *u, const real *p, const real *yref, real *res,
+                         real *Jx) {
+    wb_residuals(mp, x, u, p, yref, res, Jx);
+}
+void oracle_wb_feet(const real *mp, const real *x, real *pos /*[4][3]*/, real *vel /*[4][3]*/) {
+    wb_kin_t k;
+    wb_kinematics(mp, x, 1, &k);
+    for (int f = 0; f < 4; f++)
+        for (int i = 0; i < 3; i++) {
+            pos[3 * f + i] = k.p[f][i];
+            real s = 0;
+            for (int cc = 0; cc < 9; cc++) s += k.J[f][9 * i + cc] * x[WV + wb_xi(f, cc)];
+            vel[3 * f + i] = s;
+        }
+}
+
 void oracle_dynamics(int model_id, const real *mp, const real *x, const real *u, const real *p,
                      real *xn, real *A, real *B) {
     if (model_id == 0)
         dyn_double_integrator(mp, x, u, xn, A, B);
-    else
+    else if (model_id == 1)
         dyn_centroidal(mp, x, u, p, xn, A, B);
+    else
+        dyn_wholebody(mp, x, u, p, xn, A, B);
 }
 
 /* inequality rows  G u <= h ; act[j] = 1 if the row is enforced */
@@ -333,15 +673,15 @@ void oracle_constraints(int model_id, const real *mp, const real *p, real *G, re
         }
         return;
     }
-    const int nu = 12;
+    const int nu = (model_id == 2) ? WB_NU : 12, fo = (model_id == 2) ? WF : 0; /* forces start at u[fo] */
     const real mu = mp[MP_MU];
     memset(G, 0, sizeof(real) * 16 * nu);
     for (int f = 0; f < 4; f++) {
         const int a = p[f] > (real)0.5;
         for (int j = 0; j < 4; j++) {
             const int row = 4 * f + j;
-            G[row * nu + 3 * f + (j >> 1)] = (j & 1) ? (real)-1 : (real)1; /* +fx,-fx,+fy,-fy */
-            G[row * nu + 3 * f + 2] = -mu;
+            G[row * nu + fo + 3 * f + (j >> 1)] = (j & 1) ? (real)-1 : (real)1; /* +fx,-fx,+fy,-fy */
+            G[row * nu + fo + 3 * f + 2] = -mu;
             h[row] = 0;
             act[row] = a;
         }
@@ -500,11 +840,14 @@ static real merit(int model_id, int nx, int nu, int np, int ng, int N, const rea
     real cost = 0, viol = 0;
     real xn[MAXN], G[MAXN * MAXN], h[MAXN];
     int act[MAXN];
-    const int ny = nx + nu;
+    const int ny = (model_id == 2) ? WB_NY : nx + nu;
     for (int i = 0; i < nx; i++) viol += FABS(x0[i] - X[i]);
     for (int k = 0; k < N; k++) {
         const real *x = X + (size_t)k * nx, *u = U + (size_t)k * nu;
         const real *p = params + (size_t)k * np;
+        if (model_id == 2)
+            cost += wb_node_terms(mp, W, 0, x, u, p, yref + (per_stage ? (size_t)k * ny : 0), NULL, NULL, NULL, NULL);
+        else
         cost += stage_cost(nx, nu, W, x, u, yref + (per_stage ? (size_t)k * ny : 0));
         oracle_dynamics(model_id, mp, x, u, p, xn, NULL, NULL);
         for (int i = 0; i < nx; i++) viol += FABS(xn[i] - X[(size_t)(k + 1) * nx + i]);
@@ -518,6 +861,9 @@ static real merit(int model_id, int nx, int nu, int np, int ng, int N, const rea
             }
         }
     }
+    if (model_id == 2)
+        cost += wb_node_terms(mp, We, 0, X + (size_t)N * nx, NULL, params + (size_t)N * np, yref_e, NULL, NULL, NULL, NULL);
+    else
     for (int i = 0; i < nx; i++) {
         const real e = X[(size_t)N * nx + i] - yref_e[i];
         cost += (real)0.5 * We[i] * e * e;
@@ -537,7 +883,7 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
                  const real *params, real *X, real *U, real *stats) {
     int nx, nu, np, ng;
     if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
-    const int ny = nx + nu;
+    const int ny = (model_id == 2) ? WB_NY : nx + nu;
     const int max_sqp = (int)opt[OP_MAX_SQP], n_ipm = (int)opt[OP_N_IPM];
     const int per_stage = opt[OP_YREF_PER_STAGE] != 0;
     const real reg = opt[OP_REG], reg_e = opt[OP_REG_E];
@@ -568,8 +914,14 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
             const real *p = params + (size_t)k * np;
             const real *yr = yref + (per_stage ? (size_t)k * ny : 0);
             oracle_dynamics(model_id, mp, x, u, p, xn, A + (size_t)k * nx * nx, Bm + (size_t)k * nx * nu);
+            for (int i = 0; i < nx; i++) d[(size_t)k * nx + i] = xn[i] - X[(size_t)(k + 1) * nx + i];
+            if (model_id == 2) {   /* dense Gauss-Newton blocks J'WJ */
+                real Rd[WB_NU];
+                cost += wb_node_terms(mp, W, reg, x, u, p, yr, Q + (size_t)k * nx * nx, q + (size_t)k * nx, Rd,
+                                      r + (size_t)k * nu);
+                for (int i = 0; i < nu; i++) R[(size_t)k * nu * nu + i * nu + i] = Rd[i];
+            } else {
             for (int i = 0; i < nx; i++) {
-                d[(size_t)k * nx + i] = xn[i] - X[(size_t)(k + 1) * nx + i];
                 q[(size_t)k * nx + i] = W[i] * (x[i] - yr[i]);
                 Q[(size_t)k * nx * nx + i * nx + i] = W[i] + reg;
             }
@@ -578,6 +930,7 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
                 R[(size_t)k * nu * nu + i * nu + i] = W[nx + i] + reg;
             }
             cost += stage_cost(nx, nu, W, x, u, yr);
+            }
             if (ng > 0 && n_ipm > 0) {
                 oracle_constraints(model_id, mp, p, G + (size_t)k * MAXN * MAXN, h, act + (size_t)k * MAXN);
                 for (int j = 0; j < ng; j++) {
@@ -587,11 +940,16 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
                 }
             }
         }
+        if (model_id == 2)
+            cost += wb_node_terms(mp, We, reg_e, X + (size_t)N * nx, NULL, params + (size_t)N * np, yref_e,
+                                  Q + (size_t)N * nx * nx, q + (size_t)N * nx, NULL, NULL);
         for (int i = 0; i < nx; i++) {
+            if (model_id != 2) {
             const real e = X[(size_t)N * nx + i] - yref_e[i];
             q[(size_t)N * nx + i] = We[i] * e;
             Q[(size_t)N * nx * nx + i * nx + i] = We[i] + reg_e;
             cost += (real)0.5 * We[i] * e * e;
+            }
             dx0[i] = x0[i] - X[i];
         }
         /* 2. QP */
@@ -715,7 +1073,8 @@ int oracle_solve_batch(int model_id, int N, int B, const real *mp, const real *o
                        const real *params, real *X, real *U, int *status, real *stats, int nthreads) {
     int nx, nu, np, ng;
     if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
-    const int ny = nx + nu;
+    int ny, nye;
+    oracle_output_dims(model_id, &ny, &nye);
     const size_t syr = opt[OP_YREF_PER_STAGE] != 0 ? (size_t)N * ny : (size_t)ny;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -723,7 +1082,7 @@ int oracle_solve_batch(int model_id, int N, int B, const real *mp, const real *o
 #pragma omp parallel for schedule(dynamic, 4)
     for (int b = 0; b < B; b++) {
         status[b] = oracle_solve(model_id, N, mp, opt, W, We, x0 + (size_t)b * nx, yref + b * syr,
-                                 yref_e + (size_t)b * nx, params + (size_t)b * (N + 1) * np,
+                                 yref_e + (size_t)b * nye, params + (size_t)b * (N + 1) * np,
                                  X + (size_t)b * (N + 1) * nx, U + (size_t)b * N * nu,
                                  stats ? stats + (size_t)b * 4 : NULL);
     }

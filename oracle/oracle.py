@@ -14,7 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax")
+MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax",
+            "p_gain", "hipx", "hipy", "lhip", "l1", "l2", "res0", "res1")
+MP_DEFAULTS = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0,
+                   p_gain=50.0, hipx=0.19, hipy=0.047, lhip=0.095, l1=0.213, l2=0.213, res0=0.0, res1=0.0)
 OPT_NAMES = ("max_sqp_iter", "n_ipm", "nlp_tol", "reg", "reg_e", "mu0", "sigma", "s_min",
              "gamma", "line_search", "rho", "yref_per_stage", "tau_min")
 OPT_DEFAULTS = dict(max_sqp_iter=1, n_ipm=6, nlp_tol=0.0, reg=1e-6, reg_e=1e-5, mu0=10.0,
@@ -60,9 +63,22 @@ class Oracle:
         return tuple(x.value for x in v)  # nx, nu, np, ng
 
     def mp(self, **kw):
-        d = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0)
+        d = dict(MP_DEFAULTS)
         d.update(kw)
         return self._a([d[k] for k in MP_NAMES])
+
+    def _mp(self, mp):
+        """model parameter vector padded to the oracle's length (older callers pass the first 8)"""
+        mp = np.asarray(mp, dtype=self.dtype).ravel()
+        full = self.mp()
+        full[:mp.size] = mp
+        return full
+
+    def output_dims(self, model_id: int):
+        ny, nye = ctypes.c_int(), ctypes.c_int()
+        if self.lib.oracle_output_dims(model_id, ctypes.byref(ny), ctypes.byref(nye)):
+            raise ValueError(f"unknown model {model_id}")
+        return ny.value, nye.value
 
     def opt(self, **kw):
         d = dict(OPT_DEFAULTS)
@@ -77,7 +93,7 @@ class Oracle:
         xn = np.zeros(nx, self.dtype)
         A = np.zeros((nx, nx), self.dtype) if jac else None
         B = np.zeros((nx, nu), self.dtype) if jac else None
-        self.lib.oracle_dynamics(model_id, self._p(self._a(mp)), self._p(x), self._p(u), self._p(p),
+        self.lib.oracle_dynamics(model_id, self._p(self._mp(mp)), self._p(x), self._p(u), self._p(p),
                                  self._p(xn), self._p(A), self._p(B))
         return (xn, A, B) if jac else xn
 
@@ -87,7 +103,7 @@ class Oracle:
         G = np.zeros((ng, nu), self.dtype)
         h = np.zeros(ng, self.dtype)
         act = np.zeros(ng, np.int32)
-        self.lib.oracle_constraints(model_id, self._p(self._a(mp)), self._p(p), self._p(G),
+        self.lib.oracle_constraints(model_id, self._p(self._mp(mp)), self._p(p), self._p(G),
                                     self._p(h), self._p(act))
         return G, h, act
 
@@ -111,10 +127,13 @@ class Oracle:
         X = self._a(X, (B, N + 1, nx)).copy()
         U = self._a(U, (B, N, nu)).copy()
         params = self._a(params if np_ > 0 else np.zeros((B, N + 1, 1)))
-        yref, yref_e = self._a(yref), self._a(yref_e, (B, nx))
+        ny, nye = self.output_dims(model_id)
+        yref, yref_e = self._a(yref), self._a(yref_e, (B, nye))
         opt = self._a(opt)
         per_stage = opt[OPT_NAMES.index("yref_per_stage")] != 0
-        assert yref.shape == ((B, N, nx + nu) if per_stage else (B, nx + nu)), yref.shape
+        assert yref.shape == ((B, N, ny) if per_stage else (B, ny)), yref.shape
+        assert np.size(W) == ny and np.size(We) == nye, (np.size(W), np.size(We))
+        mp = self._mp(mp)
         if np_ > 0:
             assert params.shape == (B, N + 1, np_), params.shape
         status = np.zeros(B, np.int32)
@@ -125,6 +144,26 @@ class Oracle:
                                          int(nthreads))
         assert rc == 0
         return X, U, status, stats
+
+    # -- whole-body model (model 2) test hooks ------------------------------------
+    def wb_residuals(self, mp, x, u, p, yref=None, jac=True):
+        """residuals (reference subtracted) and their dense state Jacobian; u=None: terminal node"""
+        ny, nye = self.output_dims(2)
+        n = nye if u is None else ny
+        x, p = self._a(x, (42,)), self._a(p, (20,))
+        u = None if u is None else self._a(u, (30,))
+        yref = self._a(np.zeros(n) if yref is None else yref, (n,))
+        res = np.zeros(n, self.dtype)
+        J = np.zeros((n, 42), self.dtype) if jac else None
+        self.lib.oracle_wb_residuals(self._p(self._mp(mp)), self._p(x), self._p(u), self._p(p), self._p(yref),
+                                     self._p(res), self._p(J))
+        return (res, J) if jac else res
+
+    def wb_feet(self, mp, x):
+        x = self._a(x, (42,))
+        pos, vel = np.zeros((4, 3), self.dtype), np.zeros((4, 3), self.dtype)
+        self.lib.oracle_wb_feet(self._p(self._mp(mp)), self._p(x), self._p(pos), self._p(vel))
+        return pos, vel
 
     def shift_warm_start(self, X, U, shift):
         B, N1, nx = X.shape
