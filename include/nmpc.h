@@ -19,7 +19,7 @@
  *     reference's single worker thread, mpc.py:164,516); distinct handles are independent.
  *     ctypes releases the GIL during calls, so a worker thread may drive a handle.
  *   - layouts are batch-major, stage-major, feature-minor, fp32:
- *        x0[B][nx]  yref[B][N][ny] | [B][ny]  yref_e[B][nx]  params[B][N+1][np]
+ *        x0[B][nx]  yref[B][N][ny] | [B][ny]  yref_e[B][ny_e]  params[B][N+1][np]
  *        X[B][N+1][nx]  U[B][N][nu]  status[B]  stats[B][4]
  *     (the reference keeps [dim][node] numpy views, solver.py:88-92,169; the Python host
  *      mirror transposes at its boundary).
@@ -35,6 +35,13 @@ extern "C" {
 /* ---- models (mathematics in DESIGN.md section 3) ---- */
 #define NMPC_MODEL_DOUBLE_INTEGRATOR 0 /* nx 4  nu 2  np 0  ng 4  (BASELINE config 1) */
 #define NMPC_MODEL_CENTROIDAL        1 /* nx 12 nu 12 np 16 ng 16 (BASELINE config 2) */
+#define NMPC_MODEL_WHOLEBODY         2 /* nx 42 nu 30 np 20 ng 16, ny 82, ny_e 58 (BASELINE configs[2]):
+                                        * the problem the reference solves, x = [q18, v18, h6], u = [a18, f12]
+                                        * (solver.py:88-92,405-418); per-node params [active(4), peak(4),
+                                        * plane_point(4x3)] (solver.py:212-252); cost residuals in the order
+                                        * base(12) joint(24) acc(12) swing(4) f_reg(12) contact(12) consist(6),
+                                        * terminal base joint swing contact consist (dynamics.py:121-134,
+                                        * solver.py:108-141); model declared in DESIGN.md 3.2.  N <= 64, fp32. */
 
 /* model parameter vector, nmpc_set_model_params(): */
 #define NMPC_MP_DT    0 /* node spacing T/N                                  */
@@ -45,7 +52,13 @@ extern "C" {
 #define NMPC_MP_GZ    5 /* gravity along z (negative)                        */
 #define NMPC_MP_MU    6 /* friction coefficient (0.8, solver.py:38)          */
 #define NMPC_MP_UMAX  7 /* double integrator input box, <= 0 disables        */
-#define NMPC_MP_COUNT 8
+#define NMPC_MP_PGAIN 8 /* whole-body: Baumgarte gain of the stance constraint (W_foot_pos_constr_stab, 50) */
+#define NMPC_MP_HIPX  9 /* whole-body leg geometry: hip offset x, y; abduction link; thigh; calf            */
+#define NMPC_MP_HIPY  10
+#define NMPC_MP_LHIP  11
+#define NMPC_MP_L1    12
+#define NMPC_MP_L2    13
+#define NMPC_MP_COUNT 16 /* entries 14, 15 reserved (0) */
 
 /* status codes written to status[B] (acados numbering) */
 #define NMPC_STATUS_OK       0
@@ -71,6 +84,9 @@ typedef struct {
 
 /* Dimensions of a model.  Any out pointer may be NULL. */
 int nmpc_model_dims(int model_id, int *nx, int *nu, int *np, int *ng);
+/* Number of cost residuals of a stage (length of W and of a yref row) and of the terminal node (length of W_e,
+ * yref_e): nx + nu and nx for models 0 and 1 (y = [x; u]), 82 and 58 for the whole-body model. */
+int nmpc_model_output_dims(int model_id, int *ny, int *ny_e);
 
 /* Replaces <name>_acados_create (+ AcadosSolverHelper.setup, solver.py:68-72). */
 int nmpc_create(const nmpc_dims *dims, int device_id, void **handle);
@@ -82,7 +98,7 @@ size_t nmpc_workspace_bytes(void *handle);
 int nmpc_set_model_params(void *handle, const float *mp, int count);
 
 /* Replaces set_cost_weight_constant / set_cost_weight_terminal (solver.py:140-141) and the
- * reg_eps / reg_eps_e constructor arguments (solver.py:53-54).  host W[ny], W_e[nx]. */
+ * reg_eps / reg_eps_e constructor arguments (solver.py:53-54).  host W[ny], W_e[ny_e]. */
 int nmpc_set_weights(void *handle, const float *W, const float *W_e, float reg, float reg_e);
 
 /* Replaces set_max_iter / set_nlp_tol / set_qp_tol (solver.py:75-79, mpc.py:464-473) and
@@ -177,6 +193,11 @@ int nmpc_rollout_batch(void *handle, int B, const nmpc_rollout_cfg *cfg, const s
  * which: 0 = A~ = [A d; 0 1], 1 = B~, 2 = K~ = [K kff], 3 = A~ + B~K~ (last sweep).
  * out_host: float[256], the logical 16x16 tile row-major, zero padded.  Synchronises the device. */
 int nmpc_debug_read_tile(void *handle, int b, int k, int which, float *out_host);
+
+/* Test hooks of the whole-body kernels: raw floats of problem b's workspace, and the float offsets of its
+ * parts for horizon N: out8 = {records, Js images, Q~ images, K~ images, stage arrays, stride, NS, REC}. */
+int nmpc_debug_read_workspace(void *handle, int b, size_t offset, size_t count, float *out_host);
+int nmpc_debug_wb_layout(int N, size_t *out8);
 
 /* Diagnostic builds (-DNMPC_STAMPS) write cycle counts to dev float[B_max][16]: 8 phases
  * (linearise, IPM update+coefficients, backward, forward, last IPM update, step+write-back, -, -)

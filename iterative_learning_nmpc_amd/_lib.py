@@ -16,6 +16,7 @@ STATUS_NAMES = {0: "ok", 1: "nan", 2: "max_iter", 3: "min_step", 4: "qp_failure"
 # every symbol include/*.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "nmpc_model_dims": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "nmpc_model_output_dims": (c_int, [c_int, POINTER(c_int), POINTER(c_int)]),
     "nmpc_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     "nmpc_destroy": (None, [c_void_p]),
     "nmpc_last_error": (c_char_p, [c_void_p]),
@@ -63,6 +64,8 @@ SIGNATURES = {
                                             c_void_p, c_void_p]),
     "nmpc_debug_read_tile": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_float)]),
     "nmpc_debug_set_buffer": (c_int, [c_void_p, c_void_p]),
+    "nmpc_debug_read_workspace": (c_int, [c_void_p, c_int, c_size_t, c_size_t, POINTER(c_float)]),
+    "nmpc_debug_wb_layout": (c_int, [c_int, POINTER(c_size_t)]),
 }
 
 

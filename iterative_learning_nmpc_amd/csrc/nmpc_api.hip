@@ -9,6 +9,7 @@
 #include <string>
 
 #include "nmpc_solve.hip"
+#include "nmpc_wb.hip"
 #include "nmpc_aux.hip.inc"
 #include "nmpc_rollout.hip.inc"
 
@@ -20,6 +21,7 @@ struct Handle {
     nmpc_dims dims{};
     int device = 0;
     int nx = 0, nu = 0, np = 0, ng = 0;
+    int ny = 0, nye = 0;     // cost residuals of a stage / of the terminal node (lengths of W, yref / W_e, yref_e)
     float* ws = nullptr;
     size_t ws_bytes = 0;
     size_t ws_stride = 0;    // floats per problem
@@ -31,7 +33,7 @@ struct Handle {
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
-    float W[32]{}, We[16]{};
+    float W[96]{}, We[64]{};
     float reg = 1e-6f, reg_e = 1e-5f;
     int max_sqp = 1, n_ipm = 6, line_search = 0;
     float nlp_tol = 0.0f, qp_tol = 1e-2f;
@@ -55,7 +57,7 @@ int fail(Handle* h, int code, const std::string& msg) {
 nmpc::SolveArgs base_args(const Handle* h) {
     nmpc::SolveArgs a{};
     a.mp = h->mp;
-    std::memcpy(a.W, h->W, sizeof(a.W));
+    std::memcpy(a.W, h->W, sizeof(a.W));        // the tile-family models have ny <= 32, ny_e <= 16
     std::memcpy(a.We, h->We, sizeof(a.We));
     a.reg = h->reg; a.reg_e = h->reg_e;
     for (int j = 0; j < 16; ++j)
@@ -71,6 +73,41 @@ nmpc::SolveArgs base_args(const Handle* h) {
 
 template <class M>
 size_t ws_floats_per_problem(int N) { return nmpc::WsLayout<M>(N).stride; }
+
+// whole-body model (nmpc_wb.hip): the handle's configuration as kernel arguments
+nmpc::wb::WbArgs wb_args(const Handle* h) {
+    nmpc::wb::WbArgs a{};
+    a.mp = h->mp;
+    std::memcpy(a.W, h->W, sizeof(a.W));
+    std::memcpy(a.We, h->We, sizeof(a.We));
+    a.reg = h->reg; a.reg_e = h->reg_e;
+    a.N = h->dims.N;
+    a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm;
+    a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
+    a.gamma = h->gamma; a.tau_min = h->tau_min;
+    a.ws = h->ws;
+    return a;
+}
+
+int launch_wb(Handle* h, nmpc::wb::WbArgs a, hipStream_t st) {
+    if (h->line_search) return fail(h, NMPC_E_ARG, "the whole-body model takes full steps (line_search = 0)");
+    const nmpc::wb::WbLds L(a.N);
+    const size_t bytes = (size_t)L.total * sizeof(float);
+    if (bytes > 64 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&nmpc::wb::nmpc_wb_qp_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const long long nthreads = (long long)a.B * (a.N + 1);
+    const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
+    const int shift = a.shift;
+    for (int it = 0; it < a.max_sqp; ++it) {
+        a.it = it;
+        a.shift = (it == 0) ? shift : 0;
+        hipLaunchKernelGGL(nmpc::wb::nmpc_wb_linearize_kernel, dim3(lin_blocks), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(nmpc::wb::nmpc_wb_qp_kernel, dim3(a.B), dim3(64), bytes, st, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
 
 // One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
@@ -158,6 +195,8 @@ int nmpc_model_dims(int model_id, int* nx, int* nu, int* np, int* ng) {
     } else if (model_id == NMPC_MODEL_CENTROIDAL) {
         d[0] = nmpc::Centroidal::NX; d[1] = nmpc::Centroidal::NU;
         d[2] = nmpc::Centroidal::NP; d[3] = nmpc::Centroidal::NG;
+    } else if (model_id == NMPC_MODEL_WHOLEBODY) {
+        d[0] = nmpc::wb::NX; d[1] = nmpc::wb::NU; d[2] = nmpc::wb::NP; d[3] = nmpc::wb::NG;
     } else {
         return NMPC_E_ARG;
     }
@@ -165,6 +204,15 @@ int nmpc_model_dims(int model_id, int* nx, int* nu, int* np, int* ng) {
     if (nu) *nu = d[1];
     if (np) *np = d[2];
     if (ng) *ng = d[3];
+    return NMPC_OK;
+}
+
+int nmpc_model_output_dims(int model_id, int* ny, int* ny_e) {
+    int nx, nu;
+    if (nmpc_model_dims(model_id, &nx, &nu, nullptr, nullptr)) return NMPC_E_ARG;
+    const bool wbm = model_id == NMPC_MODEL_WHOLEBODY;
+    if (ny) *ny = wbm ? nmpc::wb::NY : nx + nu;
+    if (ny_e) *ny_e = wbm ? nmpc::wb::NYE : nx;
     return NMPC_OK;
 }
 
@@ -180,6 +228,11 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     h->dims = *dims;
     h->device = device_id;
     h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
+    nmpc_model_output_dims(dims->model_id, &h->ny, &h->nye);
+    if (dims->model_id == NMPC_MODEL_WHOLEBODY && dims->precision != 0)
+        { delete h; return fail(nullptr, NMPC_E_ARG, "the whole-body model runs in fp32 only"); }
+    if (dims->model_id == NMPC_MODEL_WHOLEBODY && dims->N > 64)
+        { delete h; return fail(nullptr, NMPC_E_ARG, "the whole-body model needs N <= 64 (lane = stage phases)"); }
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
     if (const char* v = std::getenv("NMPC_QP_VARIANT")) {
@@ -187,15 +240,15 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
         else if (!std::strcmp(v, "lean")) h->force_variant = 2;
     }
     if (e == hipSuccess) {
-        h->ws_stride = (dims->model_id == NMPC_MODEL_DOUBLE_INTEGRATOR)
-                           ? ws_floats_per_problem<nmpc::DoubleIntegrator>(dims->N)
-                           : ws_floats_per_problem<nmpc::Centroidal>(dims->N);
+        h->ws_stride = (dims->model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) ? ws_floats_per_problem<nmpc::DoubleIntegrator>(dims->N)
+                     : (dims->model_id == NMPC_MODEL_CENTROIDAL)      ? ws_floats_per_problem<nmpc::Centroidal>(dims->N)
+                                                                      : nmpc::wb::WsLayout(dims->N).stride;
         h->ws_bytes = (size_t)dims->B_max * h->ws_stride * sizeof(float);
         e = hipMalloc(reinterpret_cast<void**>(&h->ws), h->ws_bytes);
     }
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
     if (e == hipSuccess) {
-        const size_t per = (size_t)dims->N * (nx + nu) + nx + (size_t)(dims->N + 1) * (np > 0 ? np : 1);
+        const size_t per = (size_t)dims->N * h->ny + h->nye + (size_t)(dims->N + 1) * (np > 0 ? np : 1);
         e = hipMalloc(reinterpret_cast<void**>(&h->roll), (size_t)dims->B_max * per * sizeof(float));
     }
     if (e != hipSuccess) {
@@ -233,10 +286,13 @@ int nmpc_set_model_params(void* handle, const float* mp, int count) {
     if (!h || !mp) return fail(h, NMPC_E_ARG, "null argument");
     if (count != NMPC_MP_COUNT) return fail(h, NMPC_E_ARG, "model parameter vector must have NMPC_MP_COUNT entries");
     if (!(mp[NMPC_MP_DT] > 0.0f)) return fail(h, NMPC_E_ARG, "dt must be positive");
-    if (h->dims.model_id == NMPC_MODEL_CENTROIDAL &&
+    if (h->dims.model_id != NMPC_MODEL_DOUBLE_INTEGRATOR &&
         !(mp[NMPC_MP_MASS] > 0 && mp[NMPC_MP_IXX] > 0 && mp[NMPC_MP_IYY] > 0 && mp[NMPC_MP_IZZ] > 0))
         return fail(h, NMPC_E_ARG, "mass and inertia must be positive");
-    h->mp = nmpc::ModelParams{mp[0], mp[1], mp[2], mp[3], mp[4], mp[5], mp[6], mp[7]};
+    if (h->dims.model_id == NMPC_MODEL_WHOLEBODY && !(mp[NMPC_MP_L1] > 0 && mp[NMPC_MP_L2] > 0 && mp[NMPC_MP_PGAIN] >= 0))
+        return fail(h, NMPC_E_ARG, "link lengths must be positive, p_gain non-negative");
+    h->mp = nmpc::ModelParams{mp[0], mp[1], mp[2], mp[3], mp[4], mp[5], mp[6], mp[7],
+                              mp[8], mp[9], mp[10], mp[11], mp[12], mp[13], mp[14], mp[15]};
     h->mp_set = true;
     return NMPC_OK;
 }
@@ -244,11 +300,11 @@ int nmpc_set_model_params(void* handle, const float* mp, int count) {
 int nmpc_set_weights(void* handle, const float* W, const float* W_e, float reg, float reg_e) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !W || !W_e) return fail(h, NMPC_E_ARG, "null argument");
-    for (int i = 0; i < h->nx + h->nu; ++i) {
+    for (int i = 0; i < h->ny; ++i) {
         if (!(W[i] >= 0.0f)) return fail(h, NMPC_E_ARG, "weights must be non-negative");
         h->W[i] = W[i];
     }
-    for (int i = 0; i < h->nx; ++i) {
+    for (int i = 0; i < h->nye; ++i) {
         if (!(W_e[i] >= 0.0f)) return fail(h, NMPC_E_ARG, "weights must be non-negative");
         h->We[i] = W_e[i];
     }
@@ -320,6 +376,15 @@ int nmpc_shift_solve_batch(void* handle, int B, int shift, const float* x0, cons
         HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
         h->ws_dirty = false;
     }
+    if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) {
+        nmpc::wb::WbArgs w = wb_args(h);
+        w.B = B;
+        w.shift = shift > h->dims.N ? h->dims.N : shift;
+        w.yref_per_stage = yref_per_stage ? 1 : 0;
+        w.x0 = x0; w.yref = yref; w.yref_e = yref_e; w.params = params;
+        w.X = X; w.U = U; w.status = status; w.stats = stats;
+        return launch_wb(h, w, st);
+    }
     nmpc::SolveArgs a = base_args(h);
     a.B = B;
     a.shift = shift > h->dims.N ? h->dims.N : shift;
@@ -344,6 +409,7 @@ int nmpc_riccati_batch(void* handle, int Bsz, int nx, int nu, const float* Q, co
     if (!h) return NMPC_E_ARG;
     if (!Q || !R || !q || !r || !A || !B_ || !d || !dx0 || !dX || !dU) return fail(h, NMPC_E_ARG, "null argument");
     if (nx < 1 || nx > 15 || nu < 1 || nu > 16) return fail(h, NMPC_E_ARG, "need 1 <= nx <= 15, 1 <= nu <= 16");
+    if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) return fail(h, NMPC_E_ARG, "nmpc_riccati_batch needs a handle of the tile-family models");
     if (Bsz < 0 || Bsz > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
     if (Bsz == 0) return NMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -449,7 +515,27 @@ int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return read_tile<nmpc::DoubleIntegrator>(h, b, k, which, out_host);
+    if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) return fail(h, NMPC_E_ARG, "use nmpc_debug_read_workspace for the whole-body model");
     return read_tile<nmpc::Centroidal>(h, b, k, which, out_host);
+}
+
+int nmpc_debug_read_workspace(void* handle, int b, size_t offset, size_t count, float* out_host) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !out_host) return fail(h, NMPC_E_ARG, "null argument");
+    if (b < 0 || b >= h->dims.B_max || offset + count > h->ws_stride) return fail(h, NMPC_E_ARG, "index out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out_host, h->ws + (size_t)b * h->ws_stride + offset, count * sizeof(float), hipMemcpyDeviceToHost));
+    return NMPC_OK;
+}
+
+int nmpc_debug_wb_layout(int N, size_t* out8) {
+    if (!out8 || N < 1) return NMPC_E_ARG;
+    const nmpc::wb::WsLayout wl(N);
+    const nmpc::wb::StageArr sa(N);
+    out8[0] = wl.rec; out8[1] = wl.js; out8[2] = wl.qt; out8[3] = wl.kt; out8[4] = wl.arr; out8[5] = wl.stride;
+    out8[6] = (size_t)sa.NS; out8[7] = (size_t)nmpc::wb::REC;
+    return NMPC_OK;
 }
 
 }  // extern "C"

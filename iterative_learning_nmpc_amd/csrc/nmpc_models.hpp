@@ -17,6 +17,8 @@ namespace nmpc {
 
 struct ModelParams {
     float dt, mass, ixx, iyy, izz, gz, mu, umax;
+    // whole-body model (nmpc_wb_model.hpp): Baumgarte gain of the stance constraint and the leg geometry
+    float p_gain, hipx, hipy, lhip, l1, l2, res0, res1;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,946 @@
+// nmpc_wb.hip -- batched NMPC solve of the whole-body model (nx = 42, nu = 30) on gfx950: a blocked Riccati /
+// interior-point kernel family beside the 16x16 single-tile family of nmpc_solve.hip.
+//
+// Replaces, for the problem the reference actually solves (q18 + v18 + h6 | a18 + f12, solver.py:88-92,405-418),
+// the per-step solve  QuadrupedAcadosSolver.solve -> acados SQP / HPIPM  (solver.py:396-403).  Two kernels per
+// SQP iteration, as in nmpc_solve.hip:
+//   nmpc_wb_linearize_kernel  one thread per (problem, node): foot kinematics with first and second
+//        derivatives, dynamics defect and its non-trivial Jacobian blocks, the scaled dense residual Jacobian
+//        Js = sqrt(W) [J | res] of the swing / contact / consistency rows as a tile image, gradients of the
+//        diagonal residuals, friction-pyramid values.
+//   nmpc_wb_qp_kernel  one problem per wavefront, 48x48 homogeneous stage matrices as 3x3 tiles of 16x16 fp32 in
+//        the accumulator layout of v_mfma_f32_16x16x4_f32 (nmpc_tile.hpp: X'Y on registers, no data movement):
+//        prologue   Q~_k = Js'Js + diag  -- the Gauss-Newton J'WJ contraction -- on the matrix pipe, per node
+//        phase R    backward sweep: P~A~ (A~ = I + N~, only N~'s non-zero tiles multiplied), P~B~, H~ux, Huu,
+//                   H~xx on MFMA tiles; LDL' of the 30x30 Huu in column layout (lane = column, v_readlane
+//                   broadcasts) applied to [H~ux | I] -> Y, W; P~+ = H~xx - Y'Y, K~ = -W'Y on MFMA tiles
+//        phase F    forward sweep: du = K~ dx~ row-per-lane, dx+ from the model's sparse structure
+//        phase I    interior point on the friction pyramids, lane = stage, barrier terms G'DG / G'v in closed form
+//        phase S    step, status, write-back (warm-start shift folded in as an index map)
+// Stage data that does not fit the LDS (Q~, K~ images, 9 + 6 KB per stage) streams through an HBM workspace;
+// the per-stage record, the elimination columns and the transposition buffer live in the LDS (31 KB at N = 30).
+#include <hip/hip_runtime.h>
+
+#include "../../include/nmpc.h"
+#include "nmpc_wb_model.hpp"
+
+namespace nmpc {
+namespace wb {
+
+constexpr int HX = 42;                 // homogeneous coordinate of x~ = [dx; 1]
+constexpr int XT = 3, UT = 2;          // 16-wide tiles of the state (48) and input (32) dimensions
+constexpr int JT = 2;                  // K tiles of the dense residual Jacobian (22 rows)
+constexpr int IMG = TILE;              // floats of one tile image (column-major 16x16)
+constexpr int JS_FLOATS = JT * XT * IMG, QT_FLOATS = XT * XT * IMG, KT_FLOATS = UT * XT * IMG;
+
+// per-node record written by the linearisation (float offsets)
+constexpr int R_D = 0;                 // defect d[42] (+2 zeros)
+constexpr int R_HQ = 44;               // d h_ang+ / d q[3..17]: [3][16]
+constexpr int R_HF = 92;               // d h_ang+ / d f: [3][12]
+constexpr int R_CDT = 128;             // dt c_i: d h_lin+ / d f_i = cdt_i I
+constexpr int R_R = 132;               // input gradient r[30] (+2)
+constexpr int R_C = 164;               // friction pyramid values c = G u - h [16]
+constexpr int R_ACT = 180, R_COST = 181;
+constexpr int R_GQ = 184;              // gradient of the diagonal residuals on x[0..35]
+constexpr int REC = 224;
+
+struct WbArgs {
+    ModelParams mp;
+    float W[NY], We[NYE];
+    float reg, reg_e;
+    int N, B;
+    int max_sqp, n_ipm, yref_per_stage, it, shift;
+    float nlp_tol, mu0, sigma, s_min, gamma, tau_min;
+    const float* x0;
+    const float* yref;
+    const float* yref_e;
+    const float* params;
+    float* X;
+    float* U;
+    int* status;
+    float* stats;
+    float* ws;
+};
+
+__host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
+__device__ __forceinline__ int shifted_node(int k, int shift, int N) { return (k >= 1 && k <= N - shift) ? k + shift : k; }
+__device__ __forceinline__ bool shifted_stage_valid(int k, int shift, int N) { return k < N - shift; }
+
+// arrays of the lane = stage phases, feature-major [feature][stage], odd stage stride
+struct StageArr {
+    int NS, dX, dU, dXp, dUp, sv, lv, total;
+    __host__ __device__ explicit StageArr(int N) {
+        NS = (N + 1) | 1;
+        int o = 0;
+        dX = o;  o += r4(NX * NS);
+        dU = o;  o += r4(NU * NS);
+        dXp = o; o += r4(NX * NS);
+        dUp = o; o += r4(NU * NS);
+        sv = o;  o += r4(NG * NS);
+        lv = o;  o += r4(NG * NS);
+        total = o;
+    }
+};
+// workspace of one problem (float offsets)
+struct WsLayout {
+    size_t rec, js, qt, kt, arr, flag, stride;
+    __host__ __device__ explicit WsLayout(int N) {
+        size_t o = 0;
+        rec = o; o += (size_t)(N + 1) * REC;
+        js = o;  o += (size_t)(N + 1) * JS_FLOATS;
+        qt = o;  o += (size_t)(N + 1) * QT_FLOATS;
+        kt = o;  o += (size_t)N * KT_FLOATS;
+        arr = o; o += StageArr(N).total;
+        flag = o; o += 4;
+        stride = (o + 63) & ~(size_t)63;
+    }
+};
+
+// weight of the diagonal residual that sits on state index s < 36 (base / joint rows), stage and terminal
+__device__ __forceinline__ float wdiag(const WbArgs& a, int s, bool term) {
+    const int i = (s < 6) ? RY_BASE + s : (s < 18) ? RY_JOINT + (s - 6) : (s < 24) ? RY_BASE + 6 + (s - 18) : RY_JOINT + 12 + (s - 24);
+    return term ? a.We[i] : a.W[i];        // base and joint rows have the same offsets in W and W_e
+}
+__device__ __forceinline__ int yref_of_state(int s) {
+    return (s < 6) ? RY_BASE + s : (s < 18) ? RY_JOINT + (s - 6) : (s < 24) ? RY_BASE + 6 + (s - 18) : RY_JOINT + 12 + (s - 24);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Linearisation: thread t <-> (problem b, node k), k = N is the terminal node.
+__global__ __launch_bounds__(64) void nmpc_wb_linearize_kernel(const WbArgs a) {
+    const int N = a.N;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)a.B * (N + 1)) return;
+    const int b = (int)(t / (N + 1)), k = (int)(t - (long long)b * (N + 1));
+    const WsLayout wl(N);
+    float* ws = a.ws + (size_t)b * wl.stride;
+    if (a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]) return;
+    const bool term = (k == N);
+    const ModelParams& mp = a.mp;
+    const float dt = mp.dt;
+    const float* Xg = a.X + (size_t)b * (N + 1) * NX;
+    const float* Ug = a.U + (size_t)b * N * NU;
+    float* rec = ws + wl.rec + (size_t)k * REC;
+    float* js = ws + wl.js + (size_t)k * JS_FLOATS;
+
+    float x[NX], u[NU], p[NP];
+    const float* xk = Xg + (size_t)shifted_node(k, a.shift, N) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = xk[i];
+    const int ks = term ? 0 : k;
+    {
+        const bool ok = (a.shift == 0) || shifted_stage_valid(ks, a.shift, N);
+        const float* uk = Ug + (size_t)(ok ? ks + a.shift : ks) * NU;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = ok ? uk[i] : 0.0f;
+    }
+    const float* pg = a.params + ((size_t)b * (N + 1) + k) * NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = pg[i];
+    const int ny = term ? NYE : NY;
+    const float* yr = term ? a.yref_e + (size_t)b * NYE
+                           : a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) + (a.yref_per_stage ? (size_t)k * NY : 0);
+    const float* Wv = term ? a.We : a.W;
+    const int r_sw = term ? RE_SWING : RY_SWING, r_ct = term ? RE_CNT : RY_CNT, r_cs = term ? RE_CONS : RY_CONS;
+    (void)ny;
+
+    // ---- kinematics
+    BaseRot br;
+    {
+        const float th[3] = {x[WQ + 3], x[WQ + 4], x[WQ + 5]}, thd[3] = {x[WV + 3], x[WV + 4], x[WV + 5]};
+        base_rotation<true>(th, thd, br);
+    }
+    float cost = 0.0f;
+    // element (row, col) of the scaled residual Jacobian image; col 42 = scaled residual value
+    auto put_js = [&](int row, int col, float v) { js[((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)] = v; };
+
+    float tau_acc[3] = {0.f, 0.f, 0.f}, F[3] = {0.f, 0.f, 0.f};
+    float hq[3][15];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 15; ++j) hq[i][j] = 0.0f;
+
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const float ql[3] = {x[WQ + 6 + 3 * f], x[WQ + 7 + 3 * f], x[WQ + 8 + 3 * f]};
+        const float wl3[3] = {x[WV + 6 + 3 * f], x[WV + 7 + 3 * f], x[WV + 8 + 3 * f]};
+        Leg lg;
+        leg_kin<true>(mp, f, ql, wl3, lg);
+        // world position, Jacobian J (3x9 wrt xi = [r, theta, ql]) and its time derivative Jd
+        float Rb[3];
+        mv(br.R, lg.b, Rb);
+        const float pz = x[WQ + 2] + Rb[2];
+        float J[3][9], Jd[3][9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { J[i][c] = (i == c) ? 1.0f : 0.0f; Jd[i][c] = 0.0f; }
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+            float t0[3], t1[3], t2[3];
+            mv(br.Ra[aa], lg.b, t0);
+            mv(br.Rad[aa], lg.b, t1);
+            mv(br.Ra[aa], lg.bd, t2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { J[i][3 + aa] = t0[i]; Jd[i][3 + aa] = t1[i] + t2[i]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float jc[3] = {lg.Jb.m[c], lg.Jb.m[3 + c], lg.Jb.m[6 + c]};
+            const float jdc[3] = {lg.Jbd.m[c], lg.Jbd.m[3 + c], lg.Jbd.m[6 + c]};
+            float t0[3], t1[3], t2[3];
+            mv(br.R, jc, t0);
+            mv(br.Rd, jc, t1);
+            mv(br.R, jdc, t2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { J[i][6 + c] = t0[i]; Jd[i][6 + c] = t1[i] + t2[i]; }
+        }
+        const float cf = p[f], peak = p[4 + f], ppz = p[8 + 3 * f + 2];
+        // swing row: peak z_foot - ref
+        {
+            const float w = Wv[r_sw + f], sw = sqrtf(w);
+            const float res = peak * pz - yr[r_sw + f];
+            cost += 0.5f * w * res * res;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) put_js(12 + f, WQ + xi_col(f, c), sw * peak * J[2][c]);
+            put_js(12 + f, HX, sw * res);
+        }
+        // contact rows: c (J v + p_gain e_z (z - plane_z)) - ref
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float vel = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) vel += J[i][c] * x[WV + xi_col(f, c)];
+            const float w = Wv[r_ct + 3 * f + i], sw = sqrtf(w);
+            const float res = cf * (vel + (i == 2 ? mp.p_gain * (pz - ppz) : 0.0f)) - yr[r_ct + 3 * f + i];
+            cost += 0.5f * w * res * res;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                put_js(3 * f + i, WQ + xi_col(f, c), sw * cf * (Jd[i][c] + (i == 2 ? mp.p_gain * J[2][c] : 0.0f)));
+                put_js(3 * f + i, WV + xi_col(f, c), sw * cf * J[i][c]);
+            }
+            put_js(3 * f + i, HX, sw * res);
+        }
+        if (!term) {   // momentum rows of the dynamics
+            const float ff[3] = {u[WF + 3 * f], u[WF + 3 * f + 1], u[WF + 3 * f + 2]};
+            float tq[3];
+            cross(Rb, ff, tq);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { F[i] += cf * ff[i]; tau_acc[i] += cf * tq[i]; }
+            // d(arm x f)/d xi_c, c = 3..8 (arm = R b does not depend on r)
+#pragma unroll
+            for (int c = 3; c < 9; ++c) {
+                const float da[3] = {J[0][c], J[1][c], J[2][c]};
+                float tc[3];
+                cross(da, ff, tc);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) hq[i][xi_col(f, c) - 3] += dt * cf * tc[i];
+            }
+            const float ax[9] = {0.f, -Rb[2], Rb[1], Rb[2], 0.f, -Rb[0], -Rb[1], Rb[0], 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rec[R_HF + i * 12 + 3 * f + j] = dt * cf * ax[3 * i + j];
+            rec[R_CDT + f] = dt * cf;
+        }
+    }
+    // ---- consistency rows  h - A_g(q) v,  A_g v = [m rdot ; R I_b E(theta) thetadot]
+    {
+        const float thd[3] = {x[WV + 3], x[WV + 4], x[WV + 5]};
+        const float Ib[3] = {mp.ixx, mp.iyy, mp.izz};
+        float sy, cy, sx, cx;
+        sincosf(x[WQ + 4], &sy, &cy);
+        sincosf(x[WQ + 5], &sx, &cx);
+        const M3 E = {{-sy, 0.f, 1.f, cy * sx, cx, 0.f, cx * cy, -sx, 0.f}};
+        const M3 Ea[3] = {{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}},
+                          {{-cy, 0.f, 0.f, -sy * sx, 0.f, 0.f, -cx * sy, 0.f, 0.f}},
+                          {{0.f, 0.f, 0.f, cy * cx, -sx, 0.f, -sx * cy, -cx, 0.f}}};
+        float wbv[3], Iw[3], L[3];
+        mv(E, thd, wbv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Iw[i] = Ib[i] * wbv[i];
+        mv(br.R, Iw, L);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            {   // linear momentum
+                const float w = Wv[r_cs + i], sw = sqrtf(w);
+                const float res = x[WH + i] - mp.mass * x[WV + i] - yr[r_cs + i];
+                cost += 0.5f * w * res * res;
+                put_js(16 + i, WH + i, sw);
+                put_js(16 + i, WV + i, -sw * mp.mass);
+                put_js(16 + i, HX, sw * res);
+            }
+            {   // angular momentum
+                const float w = Wv[r_cs + 3 + i], sw = sqrtf(w);
+                const float res = x[WH + 3 + i] - L[i] - yr[r_cs + 3 + i];
+                cost += 0.5f * w * res * res;
+                put_js(19 + i, WH + 3 + i, sw);
+                put_js(19 + i, HX, sw * res);
+            }
+        }
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+            float t0[3], t1[3], t2[3], ew[3], iew[3], iec[3];
+            mv(br.Ra[aa], Iw, t0);
+            mv(Ea[aa], thd, ew);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { iew[i] = Ib[i] * ew[i]; iec[i] = Ib[i] * E.m[3 * i + aa]; }
+            mv(br.R, iew, t1);
+            mv(br.R, iec, t2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float sw = sqrtf(Wv[r_cs + 3 + i]);
+                put_js(19 + i, WQ + 3 + aa, -sw * (t0[i] + t1[i]));
+                put_js(19 + i, WV + 3 + aa, -sw * t2[i]);
+            }
+        }
+    }
+    // ---- diagonal residuals (base, joint) on x[0..35]: gradient and cost
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+        const float w = wdiag(a, s, term);
+        const float e = x[s] - yr[yref_of_state(s)];
+        rec[R_GQ + s] = w * e;
+        cost += 0.5f * w * e * e;
+    }
+    if (!term) {
+        // input residuals: acc on a[6..17], f_reg on f
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            float g = 0.0f;
+            if (i >= 6 && i < 18) {
+                const float w = a.W[RY_ACC + i - 6], e = u[i] - yr[RY_ACC + i - 6];
+                g = w * e; cost += 0.5f * w * e * e;
+            } else if (i >= WF) {
+                const float w = a.W[RY_FREG + i - WF], e = u[i] - yr[RY_FREG + i - WF];
+                g = w * e; cost += 0.5f * w * e * e;
+            }
+            rec[R_R + i] = g;
+        }
+        // dynamics defect
+        const float* xn_g = Xg + (size_t)shifted_node(k + 1, a.shift, N) * NX;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const float vn = x[WV + i] + dt * u[WA + i];
+            rec[R_D + WV + i] = vn - xn_g[WV + i];
+            rec[R_D + WQ + i] = x[WQ + i] + dt * vn - xn_g[WQ + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rec[R_D + WH + i] = x[WH + i] + dt * (F[i] + (i == 2 ? mp.mass * mp.gz : 0.0f)) - xn_g[WH + i];
+            rec[R_D + WH + 3 + i] = x[WH + 3 + i] + dt * tau_acc[i] - xn_g[WH + 3 + i];
+        }
+        rec[R_D + 42] = 0.0f; rec[R_D + 43] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 15; ++j) rec[R_HQ + i * 16 + j] = hq[i][j];
+        // friction pyramid
+        float fv[12], g[NG];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fv[i] = u[WF + i];
+        gdot(mp, fv, g);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) rec[R_C + j] = g[j];       // h = 0
+        reinterpret_cast<unsigned*>(rec)[R_ACT] = (a.n_ipm > 0) ? active_mask(p) : 0u;
+    }
+    rec[R_COST] = cost;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// tile helpers of the blocked sweeps
+constexpr int LDU = 36;      // LDS column stride of the 32-row elimination columns (Huu | H~ux -> W | Y)
+constexpr int LDH = 52;      // LDS column stride of the 48-row transposition buffer of H~xx
+constexpr int IPMW = 57;     // LDS row of a stage's barrier-modified input terms: rt[30] at 0, Rf[4][5] at 32
+constexpr int IPM_RF = 32;
+
+struct WbLds {
+    int colU, colX, hbuf, recb, ipm, dxv, duv, total;
+    __host__ __device__ explicit WbLds(int N) {
+        int o = 0;
+        colU = o; o += NG * 0 + 32 * LDU;
+        colX = o; o += 48 * LDU;
+        hbuf = o; o += 48 * LDH;
+        recb = o; o += 2 * 256;
+        ipm = o;  o += r4(N * IPMW);
+        dxv = o;  o += 48;
+        duv = o;  o += 32;
+        total = o;
+    }
+};
+
+__device__ __forceinline__ bool n_tile_nonzero(int k, int j) { return !((k == 0 && j == 0) || (k == 1 && j == 0) || (k == 1 && j == 1)); }
+__device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 && j == 1); }
+
+// QP + step of one SQP iteration: one problem per wavefront.
+__global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const int lane = lane_id();
+    const int q4 = lane >> 4, c = lane & 15;
+    const int N = a.N;
+    const WsLayout wl(N);
+    float* ws = a.ws + (size_t)b * wl.stride;
+    int* flag = reinterpret_cast<int*>(ws + wl.flag);
+    if (a.it > 0 && flag[0]) return;
+    const WbLds L(N);
+    const StageArr SA(N);
+    const int NS = SA.NS;
+    float* arr = ws + wl.arr;
+    float* dX = arr + SA.dX;   float* dU = arr + SA.dU;
+    float* dXp = arr + SA.dXp; float* dUp = arr + SA.dUp;
+    float* sv = arr + SA.sv;   float* lv = arr + SA.lv;
+    float* colU = smem + L.colU; float* colX = smem + L.colX; float* hbuf = smem + L.hbuf;
+    float* recb = smem + L.recb; float* ipm = smem + L.ipm;
+    float* dxv = smem + L.dxv;   float* duv = smem + L.duv;
+    const float* recs = ws + wl.rec;
+    float* Qimg = ws + wl.qt;
+    float* Kimg = ws + wl.kt;
+    float* Xg = a.X + (size_t)b * (N + 1) * NX;
+    float* Ug = a.U + (size_t)b * N * NU;
+    const float* x0 = a.x0 + (size_t)b * NX;
+    const ModelParams& mp = a.mp;
+    const float dt = mp.dt;
+#define AT(arr_, k_, i_) (arr_)[(i_) * NS + (k_)]
+    auto phase_sync = [&]() { __threadfence_block(); wave_sync(); };
+
+    // ---------------------------------------------------------------- prologue: Q~_k = Js'Js + diag (+ gradient)
+    // the Gauss-Newton contraction J'WJ of the dense residual rows on the matrix pipe
+    for (int k = 0; k <= N; ++k) {
+        const bool term = (k == N);
+        const float* js = ws + wl.js + (size_t)k * JS_FLOATS;
+        const float* rec = recs + (size_t)k * REC;
+        f32x4 J[JT][XT];
+#pragma unroll
+        for (int t = 0; t < JT; ++t)
+#pragma unroll
+            for (int j = 0; j < XT; ++j) J[t][j] = load_tile(js + (t * XT + j) * IMG, lane);
+        // gradient of the diagonal residuals: column HX (lanes c == 10 of tile column 2) and row HX
+        f32x4 gcol[XT];
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            const int row0 = 16 * i + 4 * q4;
+            gcol[i] = *reinterpret_cast<const f32x4*>(rec + R_GQ + (row0 < 36 ? row0 : 0));
+        }
+        float grow[XT];
+#pragma unroll
+        for (int j = 0; j < XT; ++j) { const int col = 16 * j + c; grow[j] = rec[R_GQ + (col < 36 ? col : 0)]; }
+#pragma unroll
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int j = 0; j < XT; ++j) {
+                f32x4 acc = zero4();
+#pragma unroll
+                for (int t = 0; t < JT; ++t) acc = xty(J[t][i], J[t][j], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
+                    float v = acc[r];
+                    if (row == col && row < NX) v += (row < 36 ? wdiag(a, row < 36 ? row : 0, term) : 0.0f) + (term ? a.reg_e : a.reg);
+                    if (col == HX && row < 36) v += gcol[i][r];
+                    if (row == HX && col < 36) v += grow[j];
+                    if (row == HX && col == HX) v = 0.0f;
+                    acc[r] = v;
+                }
+                store_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane, acc);
+            }
+    }
+    // cost, active rows, cold start of the interior point: s = max(-c, s_min), lam = mu0 / s
+    float cost_l = 0.0f, mu_l = 0.0f;
+    int nact_l = 0;
+    unsigned my_act = 0u;
+    if (lane <= N) cost_l = recs[(size_t)lane * REC + R_COST];
+    if (lane < N) {
+        const float* rec = recs + (size_t)lane * REC;
+        my_act = reinterpret_cast<const unsigned*>(rec)[R_ACT];
+        nact_l = __popc(my_act);
+        mu_l = a.mu0 * (float)nact_l;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const float s = fmaxf(-rec[R_C + j], a.s_min);
+            AT(sv, lane, j) = s;
+            AT(lv, lane, j) = a.mu0 * fast_rcp(s);
+        }
+    }
+    const float cost = wave_sum(cost_l);
+    const int n_act = (int)(wave_sum((float)nact_l) + 0.5f);
+    float mu_sum = wave_sum(mu_l);
+    const bool use_ipm = (a.n_ipm > 0) && (n_act > 0);
+    const int n_sweeps = use_ipm ? a.n_ipm : 1;
+    phase_sync();
+
+    // barrier-modified input terms of stage `lane`, lane = stage: rt = r + G'(tau/s + lam + D c), Rf = G'DG per foot
+    auto write_ipm_terms = [&](float tau) {
+        if (lane < N) {
+            const float* rec = recs + (size_t)lane * REC;
+            float* row = ipm + lane * IPMW;
+#pragma unroll
+            for (int i = 0; i < WF; ++i) row[i] = rec[R_R + i];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float D[4], v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = use_ipm && ((my_act >> (4 * f + j)) & 1u);
+                    const float s = AT(sv, lane, 4 * f + j), l = AT(lv, lane, 4 * f + j), cj = rec[R_C + 4 * f + j];
+                    const float is = fast_rcp(s);
+                    D[j] = on ? l * is : 0.0f;
+                    v[j] = on ? tau * is + l + l * is * cj : 0.0f;
+                }
+                row[WF + 3 * f + 0] = rec[R_R + WF + 3 * f + 0] + (v[0] - v[1]);
+                row[WF + 3 * f + 1] = rec[R_R + WF + 3 * f + 1] + (v[2] - v[3]);
+                row[WF + 3 * f + 2] = rec[R_R + WF + 3 * f + 2] - mp.mu * ((v[0] + v[1]) + (v[2] + v[3]));
+                row[IPM_RF + 5 * f + 0] = D[0] + D[1];
+                row[IPM_RF + 5 * f + 1] = D[2] + D[3];
+                row[IPM_RF + 5 * f + 2] = mp.mu * mp.mu * ((D[0] + D[1]) + (D[2] + D[3]));
+                row[IPM_RF + 5 * f + 3] = -mp.mu * (D[0] - D[1]);
+                row[IPM_RF + 5 * f + 4] = -mp.mu * (D[2] - D[3]);
+            }
+        }
+    };
+
+    // per-lane constants of the tile synthesis
+    // input-cost diagonal (W_acc on a[6..17], W_cnt_f_reg on f) + reg, for the diagonal element this lane may hold
+    float rdiag[UT];
+#pragma unroll
+    for (int i = 0; i < UT; ++i) {
+        const int uu = 16 * i + c;
+        float w = 0.0f;
+        if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
+        if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
+        rdiag[i] = (uu < NU) ? w + a.reg : 0.0f;
+    }
+
+    bool qp_ok = true;
+    for (int ii = 0; ii < n_sweeps; ++ii) {
+        const float tau = use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f;
+        if (ii == 0) { write_ipm_terms(tau); wave_sync(); }
+        // ------------------------------------------------------------ phase R: backward sweep
+        f32x4 P[XT][XT];
+#pragma unroll
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int j = 0; j < XT; ++j) P[i][j] = load_tile(Qimg + (size_t)N * QT_FLOATS + (i * XT + j) * IMG, lane);
+        // record of stage N-1 into the LDS; each stage prefetches the next one's (global -> registers -> LDS)
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (size_t)(N - 1) * REC + (4 * lane < REC ? 4 * lane : 0));
+            *reinterpret_cast<f32x4*>(recb + ((N - 1) & 1) * 256 + 4 * lane) = v;
+        }
+        wave_sync();
+        for (int k = N - 1; k >= 0; --k) {
+            const int kn = k > 0 ? k - 1 : 0;
+            // prefetch: next record, this stage's Q~ tiles were requested ... (Q of stage k is loaded here; the
+            // loads are issued first and consumed after the P~A~, P~B~ products)
+            const f32x4 rec_next = *reinterpret_cast<const f32x4*>(recs + (size_t)kn * REC + (4 * lane < REC ? 4 * lane : 0));
+            f32x4 Q[XT][XT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
+            const float* rk = recb + (k & 1) * 256;
+            const float* ik = ipm + k * IPMW;
+            // ---- synthesise N~ = A~ - I and B~ tiles from the record
+            f32x4 Nt[XT][XT], Bt[XT][UT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    if (!n_tile_nonzero(i, j)) { Nt[i][j] = zero4(); continue; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
+                        float v = 0.0f;
+                        if (row < 18 && col == row + 18) v = dt;
+                        if (col == HX && row < NX) v = rk[R_D + (row < NX ? row : 0)];
+                        if (row >= 39 && row < 42 && col >= 3 && col < 18) v = rk[R_HQ + ((row >= 39 && row < 42) ? row - 39 : 0) * 16 + ((col >= 3 && col < 18) ? col - 3 : 0)];
+                        Nt[i][j][r] = v;
+                    }
+                }
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < UT; ++j) {
+                    if (!b_tile_nonzero(i, j)) { Bt[i][j] = zero4(); continue; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * q4 + r, uc = 16 * j + c;
+                        float v = 0.0f;
+                        if (uc < 18 && row == uc) v = dt * dt;
+                        if (uc < 18 && row == uc + 18) v = dt;
+                        if (uc >= WF && uc < NU) {
+                            const int f = uc - WF;
+                            if (row >= 36 && row < 39 && row - 36 == f % 3) v = rk[R_CDT + f / 3];
+                            if (row >= 39 && row < 42) v = rk[R_HF + (row - 39) * 12 + f];
+                        }
+                        Bt[i][j][r] = v;
+                    }
+                }
+            // ---- P~A~ = P~ + P~N~ ,  P~B~
+            f32x4 PA[XT][XT], PB[XT][UT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i) {
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = P[i][j];
+#pragma unroll
+                    for (int kk = 0; kk < XT; ++kk)
+                        if (n_tile_nonzero(kk, j)) acc = xty(P[kk][i], Nt[kk][j], acc);
+                    PA[i][j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < UT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int kk = 0; kk < XT; ++kk)
+                        if (b_tile_nonzero(kk, j)) acc = xty(P[kk][i], Bt[kk][j], acc);
+                    PB[i][j] = acc;
+                }
+            }
+            // ---- H~ux = S~ + B~'(P~A~) ,  Huu = R~ + B~'(P~B~)  -> LDS columns
+#pragma unroll
+            for (int i = 0; i < UT; ++i) {
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+                    if (j == 2) {   // S~: the input gradient rides in column HX
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int uu = 16 * i + 4 * q4 + r;
+                            acc[r] = (c == HX - 32 && uu < NU) ? ik[uu < NU ? uu : 0] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < XT; ++kk)
+                        if (b_tile_nonzero(kk, i)) acc = xty(Bt[kk][i], PA[kk][j], acc);
+                    *reinterpret_cast<f32x4*>(colX + (16 * j + c) * LDU + 16 * i + 4 * q4) = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < UT; ++j) {
+                    f32x4 acc = zero4();
+                    {   // all four tiles: lane L > j of the elimination reads row j of column L (upper triangle)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ur = 16 * i + 4 * q4 + r, uc = 16 * j + c;
+                            float v = (ur == uc) ? rdiag[j] : 0.0f;
+                            if (ur >= WF && ur < NU && uc >= WF && uc < NU) {       // barrier block of the foot
+                                const int fr = ur - WF, fc = uc - WF;
+                                if (fr / 3 == fc / 3) {
+                                    const int ar = fr % 3, ac = fc % 3, ft = fr / 3;
+                                    const int sel = (ar == ac) ? ar : (ar + ac == 2) ? 3 : (ar + ac == 3) ? 4 : -1;
+                                    if (sel >= 0) v += ik[IPM_RF + 5 * ft + sel];
+                                }
+                            }
+                            acc[r] = v;
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < XT; ++kk)
+                            if (b_tile_nonzero(kk, i)) acc = xty(Bt[kk][i], PB[kk][j], acc);
+                    }
+                    *reinterpret_cast<f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4) = acc;
+                }
+            }
+            // ---- H = Q~ + P~A~ + N~'(P~A~) ; H~xx = (H + H')/2 through the LDS
+            f32x4 H[XT][XT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = Q[i][j] + PA[i][j];
+#pragma unroll
+                    for (int kk = 0; kk < XT; ++kk)
+                        if (n_tile_nonzero(kk, i)) acc = xty(Nt[kk][i], PA[kk][j], acc);
+                    H[i][j] = acc;
+                    *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = acc;
+                }
+            // next stage's record goes to the other LDS buffer
+            *reinterpret_cast<f32x4*>(recb + (kn & 1) * 256 + 4 * lane) = rec_next;
+            wave_sync();
+#ifdef NMPC_WB_DEBUG   // bring-up build (tools/wb_debug.py): the elimination's input and output of stage N-1
+            if (k == N - 1) {
+                float* dbg = ws + wl.js;
+                for (int i = lane; i < 32 * LDU; i += 64) dbg[i] = colU[i];
+                for (int i = lane; i < 48 * LDU; i += 64) dbg[32 * LDU + i] = colX[i];
+                for (int i = lane; i < 48 * LDH; i += 64) dbg[80 * LDU + i] = hbuf[i];
+            }
+#endif
+            // ---- LDL' of Huu in column layout applied to [H~ux | I]
+            // lanes 0..31: column `lane` of Huu; lanes 32..63: column lane-32 of I; every lane: column `lane` of H~ux
+            float Xc[NU], Cc[NU];
+            {
+                const bool is_h = lane < 32;
+                const float* pu = colU + (is_h ? lane : 0) * LDU;
+                const float* px = colX + (lane < 48 ? lane : 47) * LDU;
+#pragma unroll
+                for (int i4 = 0; i4 < 8; ++i4) {
+                    const f32x4 vu = *reinterpret_cast<const f32x4*>(pu + 4 * i4);
+                    const f32x4 vx = *reinterpret_cast<const f32x4*>(px + 4 * i4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * i4 + r;
+                        if (i < NU) {
+                            Xc[i] = is_h ? vu[r] : ((lane - 32 == i) ? 1.0f : 0.0f);
+                            Cc[i] = vx[r];
+                        }
+                    }
+                }
+            }
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const float d = bcast(Xc[j], j);
+                ok = ok && (d > 0.0f);
+                const float rs = __builtin_amdgcn_rsqf(d);
+                Xc[j] *= rs; Cc[j] *= rs;
+                const float wx = Xc[j] * rs, wc = Cc[j] * rs;
+#pragma unroll
+                for (int i = j + 1; i < NU; ++i) {
+                    const float l = bcast(Xc[i], j);
+                    Xc[i] = fmaf(-l, wx, Xc[i]);
+                    Cc[i] = fmaf(-l, wc, Cc[i]);
+                }
+            }
+            qp_ok = qp_ok && ok;
+            // transposed H for the symmetrisation (reads issued before the columns are overwritten: other buffer)
+            f32x4 Ht[XT][XT];
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    const float* ph = hbuf + (16 * i + 4 * q4) * LDH + 16 * j + c;
+                    Ht[i][j] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
+                }
+            wave_sync();
+            // write back: W (lanes 32..63 -> colU column lane-32), Y (lanes 0..47 -> colX column lane)
+            {
+                float* pw = colU + (lane >= 32 ? lane - 32 : 0) * LDU;
+                float* py = colX + (lane < 48 ? lane : 47) * LDU;
+#pragma unroll
+                for (int i4 = 0; i4 < 8; ++i4) {
+                    f32x4 vw, vy;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * i4 + r;
+                        vw[r] = (i < NU) ? Xc[i < NU ? i : 0] : 0.0f;
+                        vy[r] = (i < NU) ? Cc[i < NU ? i : 0] : 0.0f;
+                    }
+                    if (lane >= 32) *reinterpret_cast<f32x4*>(pw + 4 * i4) = vw;
+                    if (lane < 48) *reinterpret_cast<f32x4*>(py + 4 * i4) = vy;
+                }
+            }
+            wave_sync();
+#ifdef NMPC_WB_DEBUG
+            if (k == N - 1) {
+                float* dbg = ws + wl.js + 80 * LDU + 48 * LDH;
+                for (int i = lane; i < 32 * LDU; i += 64) dbg[i] = colU[i];
+                for (int i = lane; i < 48 * LDU; i += 64) dbg[32 * LDU + i] = colX[i];
+            }
+#endif
+            f32x4 Y[UT][XT], Wt[UT][UT];
+#pragma unroll
+            for (int i = 0; i < UT; ++i) {
+#pragma unroll
+                for (int j = 0; j < XT; ++j) Y[i][j] = *reinterpret_cast<const f32x4*>(colX + (16 * j + c) * LDU + 16 * i + 4 * q4);
+#pragma unroll
+                for (int j = 0; j < UT; ++j) Wt[i][j] = *reinterpret_cast<const f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4);
+            }
+            wave_sync();
+            // ---- P~+ = H~xx - Y'Y ,  K~ = -W'Y
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = 0.5f * (H[i][j] + Ht[i][j]);
+#pragma unroll
+                    for (int kk = 0; kk < UT; ++kk) acc = xty(-Y[kk][i], Y[kk][j], acc);
+                    if (i == 2 && j == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c == HX - 32 && 32 + 4 * q4 + r == HX) acc[r] = 0.0f;
+                    }
+                    P[i][j] = acc;
+                }
+#pragma unroll
+            for (int i = 0; i < UT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int kk = i; kk < UT; ++kk) acc = xty(-Wt[kk][i], Y[kk][j], acc);   // W is lower triangular
+                    store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, acc);
+                }
+        }
+        phase_sync();
+        // ------------------------------------------------------------ phase F: forward sweep
+        float* oX = use_ipm ? dXp : dX;
+        float* oU = use_ipm ? dUp : dU;
+        {
+            float v = 0.0f;
+            if (lane < NX) v = x0[lane] - Xg[lane];       // node 0 is not moved by the warm-start shift
+            if (lane == HX) v = 1.0f;
+            if (lane < 48) dxv[lane] = v;
+            if (lane < 32) duv[lane] = 0.0f;
+            if (lane < NX) AT(oX, 0, lane) = v;
+        }
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (4 * lane < REC ? 4 * lane : 0));
+            *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
+        }
+        wave_sync();
+        // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16)
+        const int urow = lane < NU ? lane : 0;
+        const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
+        for (int k = 0; k < N; ++k) {
+            const float* Kk = Kimg + (size_t)k * KT_FLOATS + krow_off;
+            const int kn = k + 1 < N ? k + 1 : k;
+            const f32x4 rec_next = *reinterpret_cast<const f32x4*>(recs + (size_t)kn * REC + (4 * lane < REC ? 4 * lane : 0));
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+            for (int j = 0; j <= HX; ++j) {
+                const float e = Kk[(j >> 4) * IMG + (j & 15) * TS];
+                float& ac = (j & 3) == 0 ? a0 : (j & 3) == 1 ? a1 : (j & 3) == 2 ? a2 : a3;
+                ac = fmaf(e, dxv[j], ac);
+            }
+            const float du = (a0 + a1) + (a2 + a3);
+            if (lane < NU) { duv[lane] = du; AT(oU, k, lane) = du; }
+            wave_sync();
+            const float* rk = recb + (k & 1) * 256;
+            float xn = 0.0f;
+            if (lane < NX) {
+                const int i = lane;
+                xn = dxv[i] + rk[R_D + i];
+                if (i < 18) xn += dt * dxv[i + 18] + dt * dt * duv[i];
+                else if (i < 36) xn += dt * duv[i - 18];
+                else if (i < 39) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) xn += rk[R_CDT + f] * duv[WF + 3 * f + (i - 36)];
+                } else {
+                    const float* hq = rk + R_HQ + (i - 39) * 16;
+                    const float* hf = rk + R_HF + (i - 39) * 12;
+#pragma unroll
+                    for (int cc = 0; cc < 15; ++cc) xn += hq[cc] * dxv[3 + cc];
+#pragma unroll
+                    for (int f = 0; f < 12; ++f) xn += hf[f] * duv[WF + f];
+                }
+            }
+            wave_sync();
+            if (lane < NX) { dxv[lane] = xn; AT(oX, k + 1, lane) = xn; }
+            *reinterpret_cast<f32x4*>(recb + (kn & 1) * 256 + 4 * lane) = rec_next;
+            wave_sync();
+        }
+        phase_sync();
+        // ------------------------------------------------------------ phase I: interior-point update, lane = stage
+        if (use_ipm) {
+            const bool live = lane < N;
+            const int k = live ? lane : 0;
+            const float* rec = recs + (size_t)k * REC;
+            float duf[12], g[NG], s[NG], l[NG], ds[NG], dl[NG], cc[NG];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) duf[i] = AT(dUp, k, WF + i);
+            gdot(mp, duf, g);
+            float rp = 0.0f, rd = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                cc[j] = rec[R_C + j];
+                s[j] = AT(sv, k, j); l[j] = AT(lv, k, j);
+                const float is = fast_rcp(s[j]);
+                ds[j] = -(g[j] + cc[j]) - s[j];
+                dl[j] = tau * is - l[j] - l[j] * is * ds[j];
+                const bool on = live && ((my_act >> j) & 1u);
+                rp = on ? fmaxf(rp, -ds[j] * is) : rp;
+                rd = on ? fmaxf(rd, -dl[j] * __builtin_amdgcn_rcpf(l[j])) : rd;
+            }
+            const float rpm = wave_max(rp), rdm = wave_max(rd);
+            const float ap = rpm > a.gamma ? a.gamma / rpm : 1.0f;
+            const float ad = rdm > a.gamma ? a.gamma / rdm : 1.0f;
+            float m_l = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const bool on = live && ((my_act >> j) & 1u);
+                s[j] += on ? ap * ds[j] : 0.0f;
+                l[j] += on ? ad * dl[j] : 0.0f;
+                if (live) { AT(sv, k, j) = s[j]; AT(lv, k, j) = l[j]; }
+                m_l += on ? s[j] * l[j] : 0.0f;
+            }
+            mu_sum = wave_sum(m_l);
+            // step <- step + ap (new step - step)
+            for (int i = lane; i < NX * NS; i += 64) { const float d = (ii == 0) ? 0.0f : dX[i]; dX[i] = d + ap * (dXp[i] - d); }
+            for (int i = lane; i < NU * NS; i += 64) { const float d = (ii == 0) ? 0.0f : dU[i]; dU[i] = d + ap * (dUp[i] - d); }
+            phase_sync();
+            if (ii + 1 < n_sweeps) {
+                write_ipm_terms(fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min));
+                wave_sync();
+            }
+        }
+    }
+    // ---------------------------------------------------------------- phase S: step
+    float sn_l = 0.0f;
+    bool bad_l = false;
+    for (int k = lane; k <= N; k += 64) {
+        for (int i = 0; i < NX; ++i) { const float v = AT(dX, k, i); bad_l = bad_l || !(fabsf(v) <= 1e30f); sn_l = fmaxf(sn_l, fabsf(v)); }
+        if (k < N)
+            for (int i = 0; i < NU; ++i) { const float v = AT(dU, k, i); bad_l = bad_l || !(fabsf(v) <= 1e30f); sn_l = fmaxf(sn_l, fabsf(v)); }
+    }
+    const float stepn = wave_max(sn_l);
+    const bool bad = __any(bad_l);
+    int status = NMPC_STATUS_MAXITER;
+    bool finished = false;
+    if (bad) { status = NMPC_STATUS_NAN; finished = true; }
+    else if (!qp_ok) { status = NMPC_STATUS_QP; finished = true; }
+    else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }
+    // new iterate = previous one (read through the warm-start shift) + step; all reads before the first write
+    if (!bad || a.shift > 0) {
+        constexpr int PRE = 8;
+        const float sc = bad ? 0.0f : 1.0f;
+        const int n_x = (N + 1) * NX, n_u = N * NU;
+        for (int base = 0; base < n_x; base += 64 * PRE) {
+            float v[PRE];
+#pragma unroll
+            for (int uu = 0; uu < PRE; ++uu) {
+                const int e = base + 64 * uu + lane, ec = e < n_x ? e : 0;
+                const int k = ec / NX, i = ec - k * NX;
+                v[uu] = Xg[ec + (shifted_node(k, a.shift, N) - k) * NX] + (bad ? 0.0f : sc * AT(dX, k, i));
+            }
+            if (a.shift > 0) phase_sync();      // a shifted read may be another lane's write target
+#pragma unroll
+            for (int uu = 0; uu < PRE; ++uu) {
+                const int e = base + 64 * uu + lane;
+                if (e < n_x) Xg[e] = v[uu];
+            }
+            if (a.shift > 0) phase_sync();
+        }
+        for (int base = 0; base < n_u; base += 64 * PRE) {
+            float v[PRE];
+#pragma unroll
+            for (int uu = 0; uu < PRE; ++uu) {
+                const int e = base + 64 * uu + lane, ec = e < n_u ? e : 0;
+                const int k = ec / NU, i = ec - k * NU;
+                const bool okk = a.shift == 0 || shifted_stage_valid(k, a.shift, N);
+                const float t = Ug[ec + (okk ? a.shift * NU : 0)];
+                v[uu] = (okk ? t : 0.0f) + (bad ? 0.0f : sc * AT(dU, k, i));
+            }
+            if (a.shift > 0) phase_sync();
+#pragma unroll
+            for (int uu = 0; uu < PRE; ++uu) {
+                const int e = base + 64 * uu + lane;
+                if (e < n_u) Ug[e] = v[uu];
+            }
+            if (a.shift > 0) phase_sync();
+        }
+    }
+    if (lane == 0) {
+        flag[0] = finished ? 1 : 0;
+        if (a.status) a.status[b] = status;
+        if (a.stats) {
+            a.stats[4 * b + 0] = cost;
+            a.stats[4 * b + 1] = stepn;
+            a.stats[4 * b + 2] = 1.0f;
+            a.stats[4 * b + 3] = (float)(a.it + 1);
+        }
+    }
+#undef AT
+}
+
+}  // namespace wb
+}  // namespace nmpc

@@ -44,7 +44,7 @@ class BatchedNmpcSolver:
         self.model_id, self.n_nodes, self.batch_max = int(model_id), int(n_nodes), int(batch_max)
         d = MODEL_DIMS[self.model_id]
         self.nx, self.nu, self.np, self.ng = d["nx"], d["nu"], d["np"], d["ng"]
-        self.ny = self.nx + self.nu
+        self.ny, self.ny_e = d["ny"], d["ny_e"]      # cost residuals of a stage / of the terminal node
         self.compute_timings = compute_timings
         self.timings = defaultdict(list)
         self.last_node = 0
@@ -111,7 +111,7 @@ class BatchedNmpcSolver:
     def set_cost_weights(self, W, W_e, reg_eps: float = 1e-6, reg_eps_e: float = 1e-5):
         W = np.ascontiguousarray(W, dtype=np.float32)
         W_e = np.ascontiguousarray(W_e, dtype=np.float32)
-        assert W.shape == (self.ny,) and W_e.shape == (self.nx,)
+        assert W.shape == (self.ny,) and W_e.shape == (self.ny_e,)
         fp = ctypes.POINTER(ctypes.c_float)
         _lib.check(self.lib.nmpc_set_weights(self._h, W.ctypes.data_as(fp), W_e.ctypes.data_as(fp),
                                              reg_eps, reg_eps_e), self._h, "nmpc_set_weights")
@@ -151,7 +151,7 @@ class BatchedNmpcSolver:
         self._chk(x0, (B, self.nx), "x0")
         per_stage = yref.dim() == 3
         self._chk(yref, (B, N, self.ny) if per_stage else (B, self.ny), "yref")
-        self._chk(yref_e, (B, self.nx), "yref_e")
+        self._chk(yref_e, (B, self.ny_e), "yref_e")
         if self.np > 0:
             self._chk(params, (B, N + 1, self.np), "params")
         self._chk(X, (B, N + 1, self.nx), "X")
@@ -190,6 +190,19 @@ class BatchedNmpcSolver:
                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))),
                    self._h, "nmpc_debug_read_tile")
         return out.reshape(16, 16).copy()   # logical (row, col), zero padded
+
+    def debug_workspace(self, b: int, offset: int, count: int) -> np.ndarray:
+        """raw floats of problem b's workspace (test hook of the whole-body kernels)"""
+        out = np.zeros(count, dtype=np.float32)
+        _lib.check(self.lib.nmpc_debug_read_workspace(self._h, b, offset, count,
+                                                      out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))),
+                   self._h, "nmpc_debug_read_workspace")
+        return out
+
+    def debug_wb_layout(self) -> dict:
+        out = (ctypes.c_size_t * 8)()
+        _lib.check(self.lib.nmpc_debug_wb_layout(self.n_nodes, out), self._h, "nmpc_debug_wb_layout")
+        return dict(zip(("rec", "js", "qt", "kt", "arr", "stride", "NS", "REC"), (int(v) for v in out)))
 
     @property
     def workspace_bytes(self) -> int:
