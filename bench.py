@@ -44,6 +44,21 @@ def algorithmic_work(nx, nu, ng, np_, N, n_sweeps):
     return flops, nbytes
 
 
+def algorithmic_work_wholebody(N, n_sweeps):
+    """SURVEY 8(d) for configs[2] (nx 42, nu 30): dense Riccati and forward terms per interior-point sweep; the
+    Gauss-Newton contraction counted as what is dense in it (22 residual rows x 43 homogeneous columns, per node --
+    the survey's 2 ny nz^2 with ny = 60 would be 18.7 MFLOP); barrier terms are closed-form 3x3 blocks."""
+    nx, nu, np_, ny, ny_e = 42, 30, 20, 82, 58
+    nz = nx + nu
+    f_riccati = N * (7 / 3 * nx ** 3 + 4 * nx * nx * nu + 2 * nx * nu * nu + nu ** 3 / 3)
+    f_fwd = N * 2 * (nu * nx + nx * nz)
+    f_gn = (N + 1) * 2 * 22 * 43 * 43
+    f_lin = (N + 1) * 6000
+    flops = n_sweeps * (f_riccati + f_fwd) + f_gn + f_lin
+    nbytes = 4 * (nx + (N + 1) * nx + N * nu + (N + 1) * np_ + N * ny + ny_e + (N + 1) * nx + N * nu)
+    return flops, nbytes
+
+
 def host_cores() -> int:
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -334,12 +349,26 @@ def torque_mode(a, world, rank, dev, dist):
             "cpu_baseline": cpu}), flush=True)
 
 
+def kernel_sources_sha() -> str:
+    """Fingerprint of the HIP sources the library is built from: ties a PMC traffic record to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "iterative_learning_nmpc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--workload", choices=("centroidal", "wholebody"), default="centroidal",
+                    help="centroidal: BASELINE configs[1], the headline (B = 1024, nx = nu = 12, N = 50); "
+                         "wholebody: configs[2] (B = 8192, nx = 42, nu = 30, N = 30)")
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default 1024 centroidal, 8192 whole-body)")
     ap.add_argument("--ipm", type=int, default=6)
     ap.add_argument("--sqp", type=int, default=1)
     ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
@@ -382,8 +411,13 @@ def main():
             dist.destroy_process_group()
         return
 
-    B, N = a.batch, 50
-    w = wl.centroidal_trot(B=B, N=N, seed=1000 * rank)
+    wbm = a.workload == "wholebody"
+    B, N = (a.batch or (8192 if wbm else 1024)), (30 if wbm else 50)
+    if wbm:
+        assert a.precision == 0, "the whole-body model runs in fp32"
+        if a.steps == 200 and a.warmup == 20:      # defaults sized for the 0.5 ms centroidal step
+            a.steps, a.warmup = 20, 3
+    w = wl.wholebody_trot(B=B, N=N, seed=1000 * rank) if wbm else wl.centroidal_trot(B=B, N=N, seed=1000 * rank)
     s = BatchedNmpcSolver(w.model_id, N, B, dev, precision=a.precision)
     s.set_model_params(w.mp)
     s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
@@ -393,8 +427,27 @@ def main():
     status = torch.empty(B, dtype=torch.int32, device=dev)
     stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
 
+    # N > 1: the one exchange step of the path rides in every timed step -- tracking error of the
+    # solved trajectories against problem 0 of the rank ("nominal"), then ONE all-gather of the [B, N+1] errors
+    # over the ranks (RCCL over xGMI).  At N = 1 there is no exchange and the step is the solve alone.
+    from iterative_learning_nmpc_amd.solver import tracking_error
+    from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors
+    ag_ev = []
+
+    def exchange(timed):
+        if world == 1:
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        err = tracking_error(t["X"], t["X"][0].contiguous(), with_weights=False)
+        e0.record()
+        err_all = all_gather_tracking_errors(err, world * B)
+        e1.record()
+        if timed:
+            ag_ev.append((e0, e1, err_all.shape))
+
     def step():       # warm-start shift by one node + solve, one call (nmpc_shift_solve_batch)
         s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats, shift=1)
+        exchange(False)
 
     # the first solve of the untouched inputs, kept for the parity figure of the cpu_baseline leg
     s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats)
@@ -418,6 +471,7 @@ def main():
         ev[i][0].record()                         # same stream the kernels are launched on
         s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], status, stats, shift=1)
         ev[i][1].record()
+        exchange(True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -450,39 +504,54 @@ def main():
 
     if rank == 0:
         n_sweeps = a.ipm if a.ipm > 0 else 1
-        flops, nbytes = algorithmic_work(s.nx, s.nu, s.ng if a.ipm > 0 else 0, s.np, N, n_sweeps)
+        flops, nbytes = (algorithmic_work_wholebody(N, n_sweeps) if wbm else
+                         algorithmic_work(s.nx, s.nu, s.ng if a.ipm > 0 else 0, s.np, N, n_sweeps))
         flops *= a.sqp
         tf = flops * B / (kernel_ms * 1e-3) / 1e12
         gbs = nbytes * B / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch
+        # PMC-measured HBM bytes per launch (tools/profile.sh writes profiles/traffic.json with the commit of the
+        # library it profiled): used only if that record belongs to THIS build of the kernels
+        traffic, traffic_source = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(f"B{B}_ipm{a.ipm}_sqp{a.sqp}")
+                rec = json.load(open(tp))
+                key = f"{'wb_' if wbm else ''}B{B}_ipm{a.ipm}_sqp{a.sqp}"
+                if rec.get("kernel_sources_sha") == kernel_sources_sha():
+                    traffic, traffic_source = rec.get(key), rec.get("source")
+                else:
+                    traffic_source = f"stale: {rec.get('source')} profiled other kernel sources; traffic withheld"
             except Exception:
                 traffic = None
         out = {
-            "metric": "MPC solves/sec (horizon-50 centroidal, batch)",
+            "metric": "MPC solves/sec (horizon-30 whole-body, batch)" if wbm else "MPC solves/sec (horizon-50 centroidal, batch)",
             "value": world * B * a.steps / elapsed, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if a.precision == 0 else "f32 (bf16 barrier product)", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if a.precision == 0 else 4}]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 "
-                                   f"{'fp32' if a.precision == 0 else 'mixed precision (bf16 MFMA barrier product, fp32 Riccati)'}, "
-                                   f"{a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step",
-                       "global_batch": world * B, "horizon": N, "parallelism": f"dp{world} (independent problems, no collective)"},
+            "config": {"workload": (f"configs[2]: batch={B}/GPU whole-body 18-DoF quadruped NMPC nx=42 nu=30 N=30 fp32, friction-pyramid + "
+                                    f"stance constraints, {a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step") if wbm else
+                                   (f"configs[{1 if a.precision == 0 else 4}]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 "
+                                    f"{'fp32' if a.precision == 0 else 'mixed precision (bf16 MFMA barrier product, fp32 Riccati)'}, "
+                                    f"{a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step"),
+                       "global_batch": world * B, "horizon": N,
+                       "parallelism": f"dp{world} (independent problems; " + ("no collective)" if world == 1 else
+                                      f"one all-gather of the [{B},{N + 1}] tracking errors per step, backend {dist.get_backend()})")},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 5 % of the solve call)", "kernel_ms": kernel_ms,
+                         "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": ("nmpc_wb_qp_kernel (+ nmpc_wb_linearize_kernel)" if wbm else
+                                    "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 5 % of the solve call)"), "kernel_ms": kernel_ms,
                          "flops_per_solve": flops, "bytes_per_solve": nbytes,
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
-                         "binds": "dependent-issue latency of the serial stage recursion, one wave per SIMD (rocprofv3, "
-                                  "profiles/r01_solve_b1024.md: MFMA pipe busy 26 % of wave cycles, VALU 34 %, stalls 27 %); "
-                                  "neither HBM nor the MFMA peak"},
+                         "binds": "instruction issue of one wave per SIMD along the serial stage recursion (MFMA + VALU + LDS of a wave "
+                                  "do not overlap; profiles/): neither HBM nor the MFMA peak"},
             "failed_problems": bad, "cold_start": cold,
         }
+        if world > 1 and ag_ev:
+            out["allgather"] = {"ms": float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in ag_ev])), "backend": dist.get_backend(),
+                                "ranks": world, "gathered_shape": list(ag_ev[0][2]), "per_step": 1}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, a.ipm, min(B, 1024), first if (a.sqp == 1 and a.precision == 0) else None)
+            out["cpu_baseline"] = cpu_baseline(w, a.ipm, min(B, 256 if wbm else 1024), first if (a.sqp == 1 and a.precision == 0) else None)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()
