@@ -4,8 +4,8 @@
 //   x = [q(18) = r(3), (yaw,pitch,roll), joints(12) | v(18) = qdot | h(6) centroidal momentum]
 //   u = [a(18) = vdot | f[4][3] world forces, feet FL,FR,RL,RR]
 //   p = [c(4) active, peak(4), plane_point(4x3)]                    (solver.py:212-252)
-// The symbolic model lives in the absent contact_tamp; the mathematics declared in DESIGN.md 3.2 (and restated
-// by oracle/nmpc_oracle.c, model 2) is evaluated here lane-locally, one thread per (problem, node):
+// The symbolic model lives in the absent contact_tamp; the mathematics declared in DESIGN.md 3.2 (restated
+// by the test oracle as its model 2) is evaluated here lane-locally, one thread per (problem, node):
 //   semi-implicit Euler  v+ = v + dt a, q+ = q + dt v+, h_lin+ = h_lin + dt (sum c_i f_i + m g),
 //   h_ang+ = h_ang + dt sum c_i (p_i(q) - r) x f_i ; legs = hip abduction (x), thigh (y), knee (y), point foot.
 // Residuals of the Gauss-Newton cost (order of W / yref, ny = 82; terminal ny_e = 58 without acc, f_reg):
