@@ -1,0 +1,137 @@
+"""The reference-shaped facade (`QuadrupedAcadosSolver`, `LocomotionMPC`) driven with the reference's own call
+sequence (mpc_controller/mpc.py:317-369,464-473; utils/solver.py:153-394).  Without a GPU: everything up to the
+solve -- the dict views, their shapes and names, and the arrays `update_solver` hands to the C-ABI."""
+import numpy as np
+import pytest
+
+from iterative_learning_nmpc_amd import wholebody as wb
+from iterative_learning_nmpc_amd import workloads as wl
+from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC, N_SQP_FIRST
+from iterative_learning_nmpc_amd.quadruped_solver import QuadrupedAcadosSolver
+
+
+def _state(seed=0):
+    rng = np.random.default_rng(seed)
+    q = np.zeros(18); v = np.zeros(18)
+    q[:2] = rng.normal(0, 0.05, 2); q[2] = 0.29; q[3:6] = rng.normal(0, 0.05, 3); q[6:] = wb.Q_HOME + rng.normal(0, 0.1, 12)
+    v[:6] = rng.normal(0, 0.2, 6); v[6:] = rng.normal(0, 0.2, 12)
+    return q, v
+
+
+def test_surface_of_the_reference_solver_is_present():
+    mpc = LocomotionMPC(print_info=False)
+    s = mpc.solver
+    for name in ("init", "solve", "reset", "update_cost", "set_cost_weights", "set_contact_restriction", "set_max_iter",
+                 "set_nlp_tol", "set_qp_tol", "warm_start_solver", "update_solver", "setup_reference", "setup_initial_state",
+                 "init_contacts_parameters", "setup_cnt_status", "setup_contact_loc", "setup_initial_feet_pos", "print_timings"):
+        assert callable(getattr(s, name)), name
+    N = mpc.config_opt.n_nodes
+    assert N == 25 and abs(s.dt_nodes - 0.04) < 1e-12                        # mpc_opt.py:11-13
+    d = s.dyn
+    assert s.states[d.q.name].shape == (18, N + 1) and s.states[d.h.name].shape == (6, N + 1)      # [dim, node] views
+    assert s.inputs[d.a.name].shape == (18, N)
+    for f in d.feet:
+        assert s.inputs[f"f_{f.frame_name}_{d.name}"].shape == (3, N)                               # solver.py:319
+        assert s.params[f.active.name].shape == (1, N + 1) and s.params[f.plane_point.name].shape == (3, N + 1)
+    assert s.cost_ref[d.base_cost.name].shape == (12, N) and s.cost_ref_terminal[d.swing_cost.name].shape == (4,)
+    assert [d.base_cost.name, d.joint_cost.name, d.acc_cost.name, d.swing_cost.name] == ["base_cost", "joint_cost", "acc_cost", "sw_cost"]
+    assert s.q_sol_euler.shape == (N + 1, 18) and s.f_sol.shape == (N, 4, 3) and s.dt_node_sol.shape == (N,)
+
+
+def test_optimize_call_sequence_fills_the_views_as_the_reference_does():
+    mpc = LocomotionMPC(print_info=False)
+    mpc.set_command(np.array([0.3, 0., 0.]), 0.)
+    q, v = _state()
+    args = mpc.solver_inputs(q, v)
+    assert len(args) == 10 and args[0] == 0                                   # init's ten positional arguments
+    s, d, N = mpc.solver, mpc.solver.dyn, mpc.config_opt.n_nodes
+    s.init(*args)
+    cnt = mpc.contact_planner.get_contacts(0, N + 1)
+    base_ref, base_ref_e = mpc.compute_base_ref_vel_tracking(q)
+    feet = wb.feet_position_w(q)
+    for i, f in enumerate(d.feet):
+        act = s.params[f.active.name][0]
+        assert act[0] == 1                                                    # i_node == 0: every foot starts in contact
+        assert (act[1:] == cnt[i, 1:]).all()
+        assert (s.params[f.peak.name][0] == 1 - cnt[i]).all()                 # opt_peak (config_abstract.py:56)
+        assert (s.params[f.p_gain.name] == 50.).all() and (s.params[f.range_radius.name] == 1e10).all()
+        assert (s.params[f.plane_normal.name] == np.array([0, 0, 1.])[:, None]).all()
+        next_swing = int(np.argmin(act))
+        assert np.allclose(s.params[f.plane_point.name][:, :next_swing], feet[i][:, None])      # stance-foot anchoring
+        assert (s.params[f.plane_point.name][:, next_swing:] == 0).all()
+    assert (s.cost_ref[d.base_cost.name] == base_ref[:, None]).all() and (s.cost_ref_terminal[d.base_cost.name] == base_ref_e).all()
+    assert (s.cost_ref[d.swing_cost.name] == 0.05).all()
+    assert np.allclose(s.cost_ref[d.joint_cost.name][:12, 3], wb.Q_HOME) and (s.cost_ref[d.joint_cost.name][12:] == 0).all()
+    p = s.pack_problem()
+    dims = wl.MODEL_DIMS[wl.MODEL_WHOLEBODY]
+    assert p["x0"].shape == (1, 42) and p["yref"].shape == (1, N, dims["ny"]) and p["yref_e"].shape == (1, dims["ny_e"])
+    assert p["params"].shape == (1, N + 1, 20) and p["X"].shape == (1, N + 1, 42) and p["U"].shape == (1, N, 30)
+    assert np.allclose(p["x0"][0, :18], q) and np.allclose(p["x0"][0, 18:36], v)
+    assert np.allclose(p["x0"][0, 36:], wb.centroidal_momentum(q, v, 15.0, [0.11, 0.27, 0.33]))    # pin_data.hg
+    assert np.allclose(p["X"][0, 0], p["x0"][0]) and (p["X"][0, 1:] == 0).all()   # first call: no warm start (solver.py:386-388)
+    assert np.allclose(p["yref"][0, :, :12], base_ref) and np.allclose(p["yref"][0, :, 48:52], 0.05)
+    n_st = p["params"][0, :N, :4].sum(1)
+    assert np.allclose(p["yref"][0, :, 54::3].sum(1), 15.0 * 9.81 * (n_st > 0))    # gravity share [decl]
+    W, We = wl.wholebody_weights(mpc.config_cost)
+    assert np.array_equal(s._W, W) and np.array_equal(s._W_e, We)
+
+
+def test_first_solve_policy_and_warm_start_shift():
+    mpc = LocomotionMPC(print_info=False)
+    s, d, N = mpc.solver, mpc.solver.dyn, mpc.config_opt.n_nodes
+    mpc.set_convergence_on_first_iter()
+    assert s._opts["max_iter"] == N_SQP_FIRST and abs(s._opts["nlp_tol"] - 0.01) < 1e-12 and abs(s._opts["qp_tol"] - 1e-3) < 1e-12
+    mpc.first_solve = False
+    mpc.set_convergence_on_first_iter()
+    assert s._opts["max_iter"] == 1 and s._opts["nlp_tol"] == 0.1
+    # pretend a solve happened: a recognisable solution, then init at node 2 shifts it by two nodes (solver.py:304-342)
+    rng = np.random.default_rng(1)
+    X, U = rng.normal(size=(1, N + 1, 42)), rng.normal(size=(1, N, 30))
+    s.parse_sol(X, U)
+    assert np.array_equal(s.q_sol_euler, X[0, :, :18]) and np.array_equal(s.f_sol, U[0, :, 18:].reshape(N, 4, 3))
+    q, v = _state(3)
+    mpc.current_opt_node = 2
+    s.init(*mpc.solver_inputs(q, v))
+    p = s.pack_problem()
+    assert np.array_equal(p["X"][0, 1:N - 1], X[0, 3:])                       # states 1..N-2 <- old 3..N
+    assert np.array_equal(p["X"][0, N - 1:], X[0, N - 1:])                    # the tail keeps its values (repeat_last=False)
+    assert np.array_equal(p["U"][0, :N - 2], U[0, 2:])
+    assert (p["U"][0, N - 2:, 18:] == 0).all()                                # force tail zeroed (solver.py:320)
+    assert np.array_equal(p["U"][0, N - 2:, :18], U[0, N - 2:, :18])          # acceleration tail untouched
+    assert s.last_node == 2
+
+
+def test_batched_views_and_raibert_planner():
+    B = 3
+    mpc = LocomotionMPC(print_info=False, batch=B, n_nodes=30)
+    q = np.stack([_state(i)[0] for i in range(B)]); v = np.stack([_state(i)[1] for i in range(B)])
+    mpc.set_command(np.array([0.2, 0.1, 0.]), 0.1)
+    mpc.solver.init(*mpc.solver_inputs(q, v))
+    p = mpc.solver.pack_problem()
+    assert p["x0"].shape == (B, 42) and p["params"].shape == (B, 31, 20) and p["yref"].shape == (B, 30, 82)
+    single = LocomotionMPC(print_info=False, n_nodes=30)
+    single.set_command(np.array([0.2, 0.1, 0.]), 0.1)
+    single.solver.init(*single.solver_inputs(q[1], v[1]))
+    p1 = single.solver.pack_problem()
+    for k in p:
+        assert np.allclose(p[k][1], p1[k][0]), k
+    # Raibert footstep plan -> plane points and base references from the plan (mpc.py:335-344, solver.py:254-276)
+    r = LocomotionMPC(print_info=False, contact_planner="raibert")
+    r.set_command(np.array([0.3, 0., 0.]), 0.)
+    qq, vv = _state(5)
+    args = r.solver_inputs(qq, vv)
+    assert args[8].shape == (4, 26, 3)
+    r.solver.init(*args)
+    f0 = r.solver.dyn.feet[0]
+    assert r.solver.restrict_cnt and (r.solver.params[f0.range_radius.name] == r.config_cost.cnt_radius).all()
+    assert np.allclose(r.solver.cost_ref[f0.pos_cost.name], args[8][0, 1:, :].T)
+
+
+def test_solve_without_a_device_fails_loudly():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    mpc = LocomotionMPC(print_info=False)
+    q, v = _state()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mpc.optimize(q, v)

@@ -136,10 +136,19 @@ def test_double_integrator_box_constraints(dev, oracle64, oracle32):
     Xo, Uo, _, _ = _oracle_solve(oracle64, w, n_ipm=8)
     assert np.abs(U).max() <= 1.0 + 1e-4          # box respected
     assert np.abs(Uo).max() > 0.9                   # and it is active
-    assert rel(X, Xo) < 1e-4 and rel(U, Uo) < 1e-4, (rel(X, Xo), rel(U, Uo))
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))      # measured 2.9e-7 / 4.4e-7 (tools/parity_floor.py)
 
 
-@pytest.mark.parametrize("n_ipm,sqp", [(0, 1), (6, 1), (6, 3), (0, 15)])
+def _within_tolerance(e, floor):
+    """The stated bar, 1e-5 relative L2 against the fp64 oracle.  The fp32 oracle is the same algorithm in float with
+    the CPU's summation order -- the kernels contract in the order of the matrix instruction, so neither is bit-equal
+    to the other; where the CPU's own fp32 error approaches the bar (measured: 7.8e-6 after three SQP iterations,
+    1.65e-5 with a binding friction pyramid, tools/parity_floor.py) the device may sit at 1.5 x that floor."""
+    return e < 1e-5 or e < 1.5 * floor
+
+
+# (6, 15) is the reference's first-solve policy (6 IPM x 15 SQP, mpc.py:464-473)
+@pytest.mark.parametrize("n_ipm,sqp", [(0, 1), (6, 1), (6, 3), (0, 15), (6, 15)])
 def test_centroidal_solve_parity(dev, oracle64, oracle32, n_ipm, sqp):
     """Config 2 shapes (nx=nu=12, N=50) at a batch the oracle finishes in seconds."""
     from iterative_learning_nmpc_amd import workloads as wl
@@ -154,12 +163,15 @@ def test_centroidal_solve_parity(dev, oracle64, oracle32, n_ipm, sqp):
     print(f"n_ipm={n_ipm} sqp={sqp}: gpu-vs-f64 X {eX:.2e} U {eU:.2e}; gpu-vs-f32 X {rel(X, X32):.2e} "
           f"U {rel(U, U32):.2e}; f32-vs-f64 floor {floor:.2e}")
     assert np.array_equal(st, st64)
-    assert eX < 1e-5 * max(1.0, 2 * sqp) and eU < 1e-5 * max(1.0, 2 * sqp)
+    # measured gpu-vs-fp64 (X / U): 4.4e-6 / 9e-7, 4.3e-6 / 1.0e-6, 1.02e-5 / 1.3e-6 (fp32 oracle itself 7.8e-6), 9.7e-7 / 2.2e-7,
+    # 1.0e-6 / 2.3e-7: fifteen iterations contract the rounding differences, they do not amplify them
+    assert _within_tolerance(eX, rel(X32, X64)) and eU < 1e-5, (eX, eU, floor)
+    assert rel(X, X32) < 1e-5 and rel(U, U32) < 1e-5                 # and against the fp32 oracle (measured <= 6.2e-6)
     assert np.allclose(stats[:, 0], stats64[:, 0], rtol=1e-4)       # cost at linearisation
     assert np.array_equal(stats[:, 3], stats64[:, 3])               # iteration count
 
 
-def test_centroidal_active_friction(dev, oracle64):
+def test_centroidal_active_friction(dev, oracle64, oracle32):
     """Low friction makes the pyramid active: constraints hold, parity at the fp32 floor of an
     ill-conditioned barrier system (bound documented in DESIGN.md 3.3)."""
     from iterative_learning_nmpc_amd import workloads as wl
@@ -173,7 +185,9 @@ def test_centroidal_active_friction(dev, oracle64):
     c = np.moveaxis(w.params[:, :50, :4], 2, 2)
     viol = np.maximum(np.abs(f[..., :2]).max(-1) - 0.3 * f[..., 2], 0) * c
     assert viol.max() < 1e-3
-    assert rel(X, X64) < 1e-4 and rel(U, U64) < 1e-4, (rel(X, X64), rel(U, U64))
+    X32, U32, _, _ = _oracle_solve(oracle32, w, n_ipm=6)
+    # measured 1.8e-5 / 5.6e-6 with the fp32 oracle itself at 1.65e-5 / 4.6e-6: the stiff barrier system, not the kernel
+    assert _within_tolerance(rel(X, X64), rel(X32, X64)) and rel(U, U64) < 1e-5, (rel(X, X64), rel(U, U64), rel(X32, X64))
 
 
 def test_centroidal_line_search_and_status(dev, oracle64):
@@ -183,9 +197,10 @@ def test_centroidal_line_search_and_status(dev, oracle64):
     s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2, line_search=1)
     X, U, st, stats = _gpu_solve(s, w)
     X64, U64, st64, stats64 = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2, line_search=1)
-    same = stats[:, 2] == stats64[:, 2]                 # identical step lengths chosen
-    assert same.mean() > 0.8
-    assert rel(X[same], X64[same]) < 1e-4
+    # every problem of the batch backtracks to the same step length as the oracle (a merit value within rounding of the
+    # acceptance threshold could flip one; none does on this seed, and the assertion is on the whole batch)
+    assert np.array_equal(stats[:, 2], stats64[:, 2])
+    assert rel(X, X64) < 1e-5 and rel(U, U64) < 1e-5, (rel(X, X64), rel(U, U64))       # measured 8.9e-7 / 2.4e-7
     # NaN input -> status 1 for that problem only
     w2 = wl.centroidal_trot(B=4, N=50, seed=5)
     w2.x0[2, 0] = np.nan
@@ -297,7 +312,7 @@ def test_odd_batches_and_horizons(dev, oracle64, model, B, N):
     X, U, st, stats = _gpu_solve(s, w)
     Xo, Uo, sto, statso = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2)
     assert np.array_equal(st, sto)
-    assert rel(X, Xo) < 3e-5 and rel(U, Uo) < 3e-5, (rel(X, Xo), rel(U, Uo))
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))           # measured <= 2.3e-6
 
 
 def test_per_problem_early_exit(dev, oracle64):
@@ -311,10 +326,11 @@ def test_per_problem_early_exit(dev, oracle64):
     X, U, st, stats = _gpu_solve(s, w)
     Xo, Uo, sto, statso = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=10, nlp_tol=0.5)
     assert len(set(statso[:, 3].tolist())) > 1, "test needs problems stopping at different iterations"
-    agree = stats[:, 3] == statso[:, 3]          # a step norm within rounding of the tolerance may flip
-    assert agree.mean() >= 0.9
-    assert np.array_equal(st[agree], sto[agree]) and (st[agree] == 0).all()
-    assert rel(X[agree], Xo[agree]) < 5e-5
+    # every problem stops at the oracle's iteration (a step norm within rounding of the tolerance could flip one: the
+    # closest on this seed is 3 % away from it)
+    assert np.array_equal(stats[:, 3], statso[:, 3])
+    assert np.array_equal(st, sto) and (st == 0).all()
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5                                      # measured 9e-7 / 1.9e-7
 
 
 def test_handle_reuse_after_riccati_and_argument_errors(dev, oracle64):

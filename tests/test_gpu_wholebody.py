@@ -198,3 +198,64 @@ def test_wholebody_api_limits(dev):
     s.set_line_search(True)
     with pytest.raises(NmpcError):
         _gpu_solve(s, w)                                               # the whole-body model takes full steps
+
+
+def _robot_state(seed=0):
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    rng = np.random.default_rng(seed)
+    q = np.zeros(18); v = np.zeros(18)
+    q[:2] = rng.normal(0, 0.05, 2); q[2] = 0.29; q[3:6] = rng.normal(0, 0.05, 3); q[6:] = wbk.Q_HOME + rng.normal(0, 0.1, 12)
+    v[:6] = rng.normal(0, 0.2, 6); v[6:] = rng.normal(0, 0.2, 12)
+    return q, v
+
+
+def test_facade_optimize_is_the_oracle_solution_of_its_packed_problem(dev, oracle64):
+    """`LocomotionMPC.optimize` through the reference-shaped facade (mpc.py:317-369 -> solver.py:355-429): the first
+    solve with the reference's first-solve policy (15 SQP, tolerances / 10: mpc.py:464-473), then a warm-started
+    steady-state solve one node later -- both equal the oracle's solution of the arrays `update_solver` packed."""
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    mpc = LocomotionMPC(print_info=False, n_nodes=30, device=dev)
+    mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+    q, v = _robot_state(0)
+    s = mpc.solver
+
+    def oracle_of_packed(max_sqp, nlp_tol):
+        p = s._problem
+        W, We = s._W, s._W_e
+        opt = oracle64.opt(max_sqp_iter=max_sqp, n_ipm=6, nlp_tol=nlp_tol, yref_per_stage=1, reg=mpc.config_cost.reg_eps,
+                           reg_e=mpc.config_cost.reg_eps_e)
+        return oracle64.solve_batch(2, 30, s.mp, opt, W, We, p["x0"], p["yref"], p["yref_e"], p["params"], p["X"], p["U"])
+
+    mpc.set_convergence_on_first_iter()
+    q_sol, v_sol, a_sol, f_sol, dt_sol = mpc.optimize(q, v)
+    assert q_sol.shape == (31, 18) and v_sol.shape == (31, 18) and a_sol.shape == (30, 18) and f_sol.shape == (30, 4, 3)
+    assert np.allclose(dt_sol, s.dt_nodes) and np.allclose(q_sol[0], q, atol=1e-5)
+    Xo, Uo, sto, statso = oracle_of_packed(15, 0.01)
+    assert s.status[0] == sto[0] and s.stats[0, 3] == statso[0, 3]
+    assert rel(q_sol, Xo[0, :, :18]) < 1e-5 and rel(a_sol, Uo[0, :, :18]) < 1e-5 and rel(f_sol.reshape(30, 12), Uo[0, :, 18:]) < 1e-5
+    mpc.first_solve = False
+    mpc.sim_step, mpc.current_opt_node = mpc.replanning_steps, 1
+    mpc.set_convergence_on_first_iter()
+    q2, v2, a2, f2, _ = mpc.optimize(q_sol[1].copy(), v_sol[1].copy())
+    Xo2, Uo2, sto2, _ = oracle_of_packed(1, 0.1)
+    assert s.last_node == 1 and s.status[0] == sto2[0]
+    assert rel(q2, Xo2[0, :, :18]) < 1e-5 and rel(f2.reshape(30, 12), Uo2[0, :, 18:]) < 1e-5
+    # the same packed problem through the batched solver: the facade adds nothing of its own
+    X, U, st, _ = _gpu_solve(s._device_solver(), type("W", (), dict(
+        x0=s._problem["x0"], yref=s._problem["yref"], yref_e=s._problem["yref_e"], params=s._problem["params"],
+        X=s._problem["X"], U=s._problem["U"])))
+    assert np.array_equal(X[0, :, :18].astype(np.float64), q2)
+
+
+def test_facade_open_loop_keeps_the_robot_up(dev):
+    """0.2 s of the reference's simulator-free rollout (mpc.py:416-462): six replans, plan followed at 1 kHz"""
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    mpc = LocomotionMPC(print_info=False, device=dev)
+    mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    q0 = np.zeros(18); q0[2] = 0.30; q0[6:] = wbk.Q_HOME
+    traj = mpc.open_loop(q0, np.zeros(18), 0.2)
+    assert traj.shape[0] in (200, 201) and traj.shape[1] == 18 and np.isfinite(traj).all()   # float clock, as the reference's loop
+    assert traj[:, 2].min() > 0.22 and np.abs(traj[:, 3:6]).max() < 0.3
+    assert traj[-1, 0] > 0.01                                                      # it walks forward
+    assert mpc.current_opt_node == 5 and mpc.solver.last_node == 5 and not mpc.first_solve
