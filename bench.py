@@ -120,7 +120,7 @@ def rollout_mode(a, world, rank, dev, dist):
     force *= rng.uniform(50, 70, (B, 1))                     # bc_experimental.yaml:32-35
     force[0] = 0.0                                           # rollout 0 of every rank: the nominal one
     push = dict(start=0.2, duration=0.3, force=force)
-    mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev)
+    mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev, footsteps=True)     # Raibert touch-downs + stance anchoring on the device
     times = []
     for it in range(a.warmup + a.steps):
         mpc.reset()
@@ -154,7 +154,8 @@ def rollout_mode(a, world, rank, dev, dist):
                                    "tracking error vs nominal + all-gather of [B,50] errors",
                        "solves_per_s": world * B * n_replans / el,
                        "ood_fraction": float(ood.float().mean().item()),
-                       "failed_rollouts": int(mpc.failed.sum().item())},
+                       "failed_rollouts": int((mpc.failed & 1).ne(0).sum().item()),
+                       "unsafe_state_rollouts": int((mpc.failed & 14).ne(0).sum().item())},
             # the solves dominate a rollout: same per-solve FLOP count as the headline (first replan: 15 SQP iterations)
             "roofline": (lambda fl: {"bound": "mfma", "achieved": fl / el / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                      "frac": fl / el / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,

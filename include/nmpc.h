@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-/* ---- models (mathematics in DESIGN.md section 3) ---- */
+/* ---- models (mathematics in DESIGN.md section 3) ----
+ * Hard limits of the kernels: models 0 and 1 live in one 16x16 tile per matrix (nx, nu <= 12 in the slot layout;
+ * nmpc_riccati_batch: nx <= 15, nu <= 16) and N <= 256 (four stages per lane); model 2 in 3x3 / 2x2 tiles with
+ * N <= 64 (one stage per lane); rollouts N <= 128.  Violations return NMPC_E_ARG. */
 #define NMPC_MODEL_DOUBLE_INTEGRATOR 0 /* nx 4  nu 2  np 0  ng 4  (BASELINE config 1) */
 #define NMPC_MODEL_CENTROIDAL        1 /* nx 12 nu 12 np 16 ng 16 (BASELINE config 2) */
 #define NMPC_MODEL_WHOLEBODY         2 /* nx 42 nu 30 np 20 ng 16, ny 82, ny_e 58 (BASELINE configs[2]):
@@ -176,16 +179,38 @@ typedef struct {
     float nlp_tol;          /* steady-state step tolerance (<= 0: none)                        */
     double sim_dt, time_horizon, nom_height, height_offset;
     float push_start, push_duration;   /* s, relative to the first replan; duration 0: no push */
+    /* Footsteps (RaiberContactPlanner.get_locations, contact_planner.py:265-322; setup_initial_feet_pos,
+     * solver.py:194-210).  0: every foot stays where foot_pos puts it for the whole rollout; 1: a stance foot keeps its
+     * position up to its next swing node, every touch-down in the window gets the Raibert target computed from the
+     * current base state and command; foot_pos is updated as feet touch down. */
+    int footsteps;
+    /* 0: one state row per replan; 1: one row per simulation step (replanning_steps rows per replan), the plan
+     * up-sampled by cubic Hermite segments as mpc.py:371-414 does (needs nodes_per_replan * dt = replanning_steps * sim_dt) */
+    int record_sim_steps;
+    float hip_offset[8];               /* Raibert: hip positions in the base frame [4][2], offsets included (mpc.py:80-91) */
+    float stance_ratio[4];             /* gait configuration (mpc_gait.py:15-21)                          */
+    float nominal_period;
+    float foot_size;                   /* z of a planned location (mpc.py:89: 0.0085)                     */
 } nmpc_rollout_cfg;
+/* bits of failed[b] (sticky over the rollout): the solver's NaN / QP failure, and the reference's unsafe-state
+ * predicates on the recorded states (check_unsafe_state_v2, DAgger/utils/Rollout_combined_controller.py:367-431;
+ * joint limits have no counterpart in the centroidal plant) */
+#define NMPC_ROLLOUT_FLAG_SOLVER        1
+#define NMPC_ROLLOUT_FLAG_ROLL          2   /* |roll| > 25 deg                      */
+#define NMPC_ROLLOUT_FLAG_PITCH         4   /* |pitch| > 25 deg                     */
+#define NMPC_ROLLOUT_FLAG_HEIGHT        8   /* base height outside [0.18, 0.45] m   */
+#define NMPC_ROLLOUT_FLAG_VEL_TRACKING 16   /* |v_xy - v_des_xy| > 0.10 m/s         */
 /* gait: dev int8 [4][nodes_per_cycle]; x: dev [B][12] in initial / out final state; v_des, w_des: dev
  * double [B][3] (commands are kept in fp64 like the reference's, so the integrated reference matches); ref_state: dev double [B][12] in/out (the controller's integrated base reference);
- * foot_pos: dev [B][4][3]; push_force: dev [B][3] or NULL; phase: host float[n_replans] recorded gait
- * phase; X, U: dev trajectories in/out (warm start of the next call); S: dev [B][n_replans][19] recorded
- * state rows [phase, rdot(3), body rates(3), z, yaw, pitch, roll, base_wrt_feet(8)]; failed: dev int [B]
- * set to 1 if any solve of the rollout returned NaN / QP failure (caller zeroes it).
- * Needs B <= B_max, N <= 128, model NMPC_MODEL_CENTROIDAL. */
+ * foot_pos: dev [B][4][3] in/out (out only with cfg.footsteps); push_force: dev [B][3] or NULL; phase: host
+ * float[n_replans] recorded gait phase of the per-replan rows; X, U: dev trajectories in/out (warm start of the next
+ * call); S: dev [B][n_rows][19], n_rows = n_replans (x replanning_steps with cfg.record_sim_steps), recorded
+ * state rows [phase, rdot(3), body rates(3), z, yaw, pitch, roll, base_wrt_feet(8)] -- the sub-vector of the
+ * reference's 44-slot row [phase, v(18), q[2:](17), base_wrt_feet(8)] (DAgger/utils/RolloutMPC.py:221) that the
+ * centroidal plant has; failed: dev int [B], NMPC_ROLLOUT_FLAG_* bits, sticky (caller zeroes it).
+ * Limits: B <= B_max, N <= 128 (contact window in the LDS), model NMPC_MODEL_CENTROIDAL. */
 int nmpc_rollout_batch(void *handle, int B, const nmpc_rollout_cfg *cfg, const signed char *gait, float *x,
-                       const double *v_des, const double *w_des, double *ref_state, const float *foot_pos,
+                       const double *v_des, const double *w_des, double *ref_state, float *foot_pos,
                        const float *push_force, const float *phase, float *X, float *U, float *S,
                        int *status, int *failed, void *stream);
 

@@ -87,7 +87,9 @@ class NmpcRolloutCfg(ctypes.Structure):
                 ("nodes_per_cycle", c_int), ("start_node", c_int), ("first_solve", c_int),
                 ("max_sqp_first", c_int), ("nlp_tol_first", c_float), ("nlp_tol", c_float),
                 ("sim_dt", ctypes.c_double), ("time_horizon", ctypes.c_double), ("nom_height", ctypes.c_double),
-                ("height_offset", ctypes.c_double), ("push_start", c_float), ("push_duration", c_float)]
+                ("height_offset", ctypes.c_double), ("push_start", c_float), ("push_duration", c_float),
+                ("footsteps", c_int), ("record_sim_steps", c_int), ("hip_offset", c_float * 8),
+                ("stance_ratio", c_float * 4), ("nominal_period", c_float), ("foot_size", c_float)]
 
 
 class NmpcDims(ctypes.Structure):

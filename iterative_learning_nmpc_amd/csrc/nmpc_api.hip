@@ -439,7 +439,7 @@ int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, cons
 }
 
 int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const signed char* gait, float* x,
-                       const double* v_des, const double* w_des, double* ref_state, const float* foot_pos,
+                       const double* v_des, const double* w_des, double* ref_state, float* foot_pos,
                        const float* push_force, const float* phase, float* X, float* U, float* S,
                        int* status, int* failed, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
@@ -454,6 +454,10 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         cfg->replanning_steps < 1 || cfg->nodes_per_cycle < 1 || cfg->start_node < 0)
         return fail(h, NMPC_E_ARG, "rollout configuration out of range");
     if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
+    if (cfg->footsteps && !(cfg->nominal_period > 0.0f)) return fail(h, NMPC_E_ARG, "footsteps need the gait period");
+    if (cfg->record_sim_steps &&
+        std::fabs(cfg->nodes_per_replan * (cfg->time_horizon / h->dims.N) - cfg->replanning_steps * cfg->sim_dt) > 1e-9)
+        return fail(h, NMPC_E_ARG, "per-step recording needs nodes_per_replan * dt_nodes = replanning_steps * sim_dt");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->ws_dirty) {
@@ -474,6 +478,13 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
     r.gait = gait; r.x = x; r.v_des = v_des; r.w_des = w_des; r.ref_state = ref_state; r.foot_pos = foot_pos;
     r.push_force = push_force; r.yref = yref; r.yref_e = yref_e; r.params = params;
     r.X = X; r.U = U; r.S = S; r.status = status; r.failed = failed;
+    r.footsteps = cfg->footsteps ? 1 : 0; r.record_sim_steps = cfg->record_sim_steps ? 1 : 0;
+    std::memcpy(r.hip_offset, cfg->hip_offset, sizeof(r.hip_offset));
+    std::memcpy(r.stance_ratio, cfg->stance_ratio, sizeof(r.stance_ratio));
+    r.nominal_period = cfg->nominal_period; r.foot_size = cfg->foot_size;
+    r.dt_nodes = cfg->time_horizon / N;
+    const int rows_per_replan = r.record_sim_steps ? cfg->replanning_steps : 1;
+    r.n_rows = cfg->n_replans * rows_per_replan;
     nmpc::SolveArgs a = base_args(h);
     a.B = B; a.yref_per_stage = 1;
     a.x0 = x; a.yref = yref; a.yref_e = yref_e; a.params = params; a.X = X; a.U = U;
@@ -484,6 +495,7 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         r.node = cfg->start_node + i * cfg->nodes_per_replan;
         r.first = cold ? 1 : 0;
         r.replan_index = i;
+        r.row0 = i * rows_per_replan;
         r.phase = phase[i];
         const float t_now = i * dt_replan;
         r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= cfg->push_start &&

@@ -7,8 +7,10 @@ Restates the control flow of mpc_controller/mpc.py on top of the batched HIP sol
     set_convergence_on_first_iter    mpc.py:464-473   (15 SQP iterations on the first solve)
     open_loop                        mpc.py:416-462   (simulator-free receding horizon: plant = plan)
     _replan / _step bookkeeping      mpc.py:171-186
-The plant is the declared centroidal model; the reference's whole-body plant,
-MuJoCo and the torque layer are outside this path.  All rollouts of a batch share the
+    RaiberContactPlanner.get_locations + stance anchoring   contact_planner.py:265-322, solver.py:194-210 (footsteps=True)
+    interpolate_state_trajectory     mpc.py:371-414   (record_sim_steps=True: one recorded row per simulation step)
+The plant is the declared centroidal model (DESIGN.md 3.2); the whole-body controller is `mpc_wholebody.py`;
+MuJoCo is outside this path.  All rollouts of a batch share the
 gait clock (they are replanned at the same nodes), which is how the reference generates its perturbed
 rollouts from one nominal rollout (data_collection_*_perturbed.py:176-247).
 """
@@ -21,9 +23,9 @@ import numpy as np
 import torch
 
 from .config import get_quadruped_config
-from .contact_planner import ContactPlanner
+from .contact_planner import ContactPlanner, RaiberContactPlanner
 from .profiling import print_timings, time_fn
-from .references import rpy_to_matrix
+from .references import _euler_rate_matrix, _hermite, rpy_to_matrix
 from .solver import BatchedNmpcSolver
 from .workloads import FEET, HIP_OFFSETS, MODEL_CENTROIDAL, model_params
 
@@ -66,8 +68,13 @@ class BatchedLocomotionMPC:
 
     def __init__(self, batch: int, gait_name: str = "trot", robot_name: str = "go2", n_nodes: int = 50,
                  device="cuda:0", sim_dt: float = 1.0e-3, height_offset: float = 0.0,
-                 compute_timings: bool = True, mass: float = 15.0, inertia=(0.11, 0.27, 0.33)):
+                 compute_timings: bool = True, mass: float = 15.0, inertia=(0.11, 0.27, 0.33),
+                 footsteps: bool = False, record_sim_steps: bool = False):
+        """footsteps: stance feet anchored, touch-downs at Raibert targets (False: the feet stay under the initial hips
+        for the whole rollout -- the stance-frozen rollouts of round 1).  record_sim_steps: one state row per
+        simulation step (the plan up-sampled as mpc.py:371-414) instead of one per replan."""
         self.batch = int(batch)
+        self.footsteps, self.record_sim_steps = bool(footsteps), bool(record_sim_steps)
         self.config_gait, self.config_opt, self.config_cost = get_quadruped_config(gait_name, robot_name)
         self.n_nodes = int(n_nodes)
         self.height_offset = height_offset
@@ -77,6 +84,10 @@ class BatchedLocomotionMPC:
         self.replanning_steps = int(1 / (self.replanning_freq * sim_dt))                # mpc.py:113
         self.nodes_per_replan = max(1, int(round(self.replanning_steps * sim_dt / self.dt_nodes)))
         self.contact_planner = ContactPlanner(FEET, self.dt_nodes, self.config_gait)
+        # footstep targets: the reference's Raibert planner with its offsets (mpc.py:80-91), stateless (cache_cnt=False)
+        offs = HIP_OFFSETS.copy(); offs[:, 2] = 0.0
+        self.raibert = RaiberContactPlanner(FEET, self.dt_nodes, self.config_gait, offs, y_offset=0.02, x_offset=0.04,
+                                            foot_size=0.0085, height_offset=height_offset, cache_cnt=False)
         self.compute_timings = compute_timings
         self.timings = defaultdict(list)
 
@@ -152,18 +163,67 @@ class BatchedLocomotionMPC:
             self.foot_pos = x[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]
         params = np.zeros((B, N + 1, 16))
         params[:, :, :4] = contacts.T[None]
-        params[:, :, 4:] = self.foot_pos.reshape(B, 1, 12)
+        if self.footsteps:
+            params[:, :, 4:] = self.plan_foot_locations(x, contacts).reshape(B, N + 1, 12)
+        else:
+            params[:, :, 4:] = self.foot_pos.reshape(B, 1, 12)
         n_stance = np.maximum(contacts[:, :N].sum(0), 1.0)
         yref = np.zeros((B, N, 24))
         yref[:, :, :12] = base_ref[:, None, :]
         yref[:, :, 14::3] = (contacts[:, :N].T * (-self.mp[5] * self.mp[1] / n_stance)[:, None])[None]
         return yref, base_ref_e, params
 
+    def plan_foot_locations(self, x: np.ndarray, contacts: np.ndarray) -> np.ndarray:
+        """[B, N+1, 4, 3]: Raibert targets from every touch-down of the window on (contact_planner.py:265-322), then a foot
+        in contact at node 0 keeps its current position up to its next swing node (solver.py:194-210, argmin and all)."""
+        B, N = self.batch, self.n_nodes
+        out = np.zeros((B, N + 1, 4, 3))
+        for b in range(B):
+            self.raibert.set_state(x[b, :3], x[b, 6:9], x[b, [5, 4, 3]], x[b, :3], self.v_des[b], self.w_des[b, 2])
+            locs = self.raibert.get_locations(self.current_opt_node, N + 1)            # [4, N+1, 3]
+            for f in range(4):
+                if contacts[f, 0]:
+                    locs[f, :int(np.argmin(contacts[f]))] = self.foot_pos[b, f]
+            out[b] = np.moveaxis(locs, 0, 1)
+        return out
+
+    def touch_down(self, params: np.ndarray) -> None:
+        """feet that stand at the node the plant has reached are where the plan put them"""
+        npr = self.nodes_per_replan
+        for f in range(4):
+            on = params[:, npr, f] > 0.5
+            self.foot_pos[on, f] = params[on, npr, 4 + 3 * f:7 + 3 * f]
+
+    def sim_step_rows(self, X: np.ndarray, params: np.ndarray, replan_index: int) -> np.ndarray:
+        """[B, replanning_steps, 19]: the plan up-sampled to the simulation rate as `interpolate_state_trajectory` does
+        (mpc.py:371-414): positions on cubic Hermite segments through (q_k, qdot_k), velocities through (v_k, a_{k-1})
+        with the reference's one-node shift of the accelerations (mpc.py:409-410); sample j at t = (j + 1) sim_dt."""
+        B, N, dtn = self.batch, self.n_nodes, self.dt_nodes
+        t_nodes = np.arange(N + 1) * dtn
+        t_q = (np.arange(self.replanning_steps) + 1) * self.sim_dt
+        seg = np.minimum(np.floor(t_q / dtn + 1e-9).astype(int), N - 1)
+        period = self.config_gait.nominal_period
+        t_w = (replan_index * self.replanning_steps + np.arange(self.replanning_steps) + 1) * self.sim_dt
+        phase = np.round(np.fmod(t_w, period) / period, 4)
+        rows = np.zeros((B, self.replanning_steps, 19))
+        for b in range(B):
+            Xb = X[b]
+            thd = np.stack([_euler_rate_matrix(Xb[k, 3:6]) @ Xb[k, [11, 10, 9]] for k in range(N + 1)])
+            pos = _hermite(t_nodes, Xb[:, :6], np.concatenate([Xb[:, 6:9], thd], axis=1), t_q)
+            acc = (Xb[1:, 6:12] - Xb[:-1, 6:12]) / dtn
+            vel = _hermite(t_nodes, Xb[:, 6:12], np.concatenate([acc[:1], acc]), t_q)
+            stands = params[b, seg, :4] > 0.5                                             # [steps, 4]
+            feet = np.where(stands[:, :, None] & self.footsteps, params[b, seg, 4:].reshape(-1, 4, 3), self.foot_pos[b][None])
+            bwf = (pos[:, None, :2] - feet[:, :, :2]).reshape(-1, 8)
+            rows[b] = np.concatenate([phase[:, None], vel, pos[:, 2:6], bwf], axis=1)
+        return rows
+
     @time_fn("optimize")
     def optimize(self, x: np.ndarray) -> Tuple[torch.Tensor, torch.Tensor]:
         """One batched replanning solve from the states x[B,12]; returns device X[B,N+1,12], U[B,N,12]."""
         s = self.solver
         yref, yref_e, params = self.build_problem(x)
+        self._params = params
         if self.first_solve:
             self.X[:] = s.to_device(np.repeat(x[:, None, :], self.n_nodes + 1, axis=1))
             self.U[:] = s.to_device(yref[:, :, 12:])
@@ -194,16 +254,22 @@ class BatchedLocomotionMPC:
             self.set_convergence_on_first_iter()
             X, _ = self.optimize(x)
             self.first_solve = False
-            rec.append(self.record_state(x, t_now))
-            times.append(t_now)
+            if self.record_sim_steps:
+                rec.append(self.sim_step_rows(X.double().cpu().numpy(), self._params, i))
+                times.extend(t_now + (np.arange(self.replanning_steps) + 1) * self.sim_dt)
+            else:
+                rec.append(self.record_state(x, t_now)[:, None, :])
+                times.append(t_now)
             x = X[:, self.nodes_per_replan, :].double().cpu().numpy()          # plant = plan
+            if self.footsteps:
+                self.touch_down(self._params)
             if push is not None and push["start"] <= t_now < push["start"] + push["duration"]:
                 x[:, 6:9] += np.asarray(push["force"]) * dt_replan / self.mp[1]
             self.sim_step += self.replanning_steps
             self.current_opt_node += self.nodes_per_replan
             self.increment_base_ref_position(self.replanning_steps)
         self._x_last = x
-        S = torch.as_tensor(np.stack(rec, axis=1), dtype=torch.float32).to(self.device).contiguous()
+        S = torch.as_tensor(np.concatenate(rec, axis=1), dtype=torch.float32).to(self.device).contiguous()
         return S, np.asarray(times)
 
     def open_loop_device(self, x0: np.ndarray, trajectory_time: float, push: Optional[dict] = None):
@@ -224,7 +290,12 @@ class BatchedLocomotionMPC:
             n_replans, self.nodes_per_replan, self.replanning_steps, self.contact_planner.nodes_per_cycle,
             self.current_opt_node, int(self.first_solve), N_SQP_FIRST, self.config_opt.nlp_tol / 10.0,
             self.config_opt.nlp_tol, self.sim_dt, self.config_opt.time_horizon, self.config_gait.nom_height,
-            self.height_offset, float(push["start"]) if push else 0.0, float(push["duration"]) if push else 0.0)
+            self.height_offset, float(push["start"]) if push else 0.0, float(push["duration"]) if push else 0.0,
+            int(self.footsteps), int(self.record_sim_steps),
+            (ctypes.c_float * 8)(*self.raibert.offset_hip_b[:, :2].ravel().tolist()),
+            (ctypes.c_float * 4)(*np.asarray(self.config_gait.stance_ratio, float).tolist()),
+            float(period), float(self.raibert.foot_size))
+        rows_per_replan = self.replanning_steps if self.record_sim_steps else 1
         gait = torch.as_tensor(np.ascontiguousarray(self.contact_planner.gait_sequence), dtype=torch.int8).to(dev)
         x = s.to_device(x0)
         v_des = torch.as_tensor(self.v_des, dtype=torch.float64).to(dev).contiguous()
@@ -232,7 +303,7 @@ class BatchedLocomotionMPC:
         ref_state = torch.as_tensor(self.base_ref_vel_tracking, dtype=torch.float64).to(dev).contiguous()
         foot = s.to_device(self.foot_pos.reshape(B, 12))
         force = s.to_device(np.asarray(push["force"])) if push else None
-        S = torch.empty(B, n_replans, 19, dtype=torch.float32, device=dev)
+        S = torch.empty(B, n_replans * rows_per_replan, 19, dtype=torch.float32, device=dev)
         failed = torch.zeros(B, dtype=torch.int32, device=dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(s.lib.nmpc_rollout_batch(
@@ -245,7 +316,11 @@ class BatchedLocomotionMPC:
         self.current_opt_node += n_replans * self.nodes_per_replan
         s.last_node = self.current_opt_node - self.nodes_per_replan
         self.base_ref_vel_tracking = ref_state.cpu().numpy()
-        self.x_final, self.failed = x, failed
+        self.x_final, self.failed = x, failed          # failed: NMPC_ROLLOUT_FLAG_* bits (include/nmpc.h)
+        if self.footsteps:
+            self.foot_pos = foot.cpu().numpy().astype(np.float64).reshape(B, 4, 3)
+        if self.record_sim_steps:
+            times = (times[:, None] + (np.arange(self.replanning_steps) + 1) * self.sim_dt).ravel()
         return S, times
 
     def record_state(self, x: np.ndarray, t: float) -> np.ndarray:
