@@ -41,6 +41,7 @@ constexpr int R_CDT = 128;             // dt c_i: d h_lin+ / d f_i = cdt_i I
 constexpr int R_R = 132;               // input gradient r[30] (+2)
 constexpr int R_C = 164;               // friction pyramid values c = G u - h [16]
 constexpr int R_ACT = 180, R_COST = 181;
+constexpr int R_ZERO = 182, R_DT = 183, R_DT2 = 220;   // constants the tile synthesis reads like any other entry
 constexpr int R_GQ = 184;              // gradient of the diagonal residuals on x[0..35]
 constexpr int REC = 224;
 
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(64) void nmpc_wb_linearize_kernel(const WbArgs a) {
             rec[R_D + WH + 3 + i] = x[WH + 3 + i] + dt * tau_acc[i] - xn_g[WH + 3 + i];
         }
         rec[R_D + 42] = 0.0f; rec[R_D + 43] = 0.0f;
+        rec[R_ZERO] = 0.0f; rec[R_DT] = dt; rec[R_DT2] = dt * dt;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -356,13 +358,12 @@ constexpr int IPMW = 57;     // LDS row of a stage's barrier-modified input term
 constexpr int IPM_RF = 32;
 
 struct WbLds {
-    int colU, colX, hbuf, recb, ipm, dxv, duv, total;
+    int colU, hbuf, recb, ipm, dxv, duv, total;
     __host__ __device__ explicit WbLds(int N) {
         int o = 0;
         colU = o; o += NG * 0 + 32 * LDU;
-        colX = o; o += 48 * LDU;
         hbuf = o; o += 48 * LDH;
-        recb = o; o += 2 * 256;
+        recb = o; o += 256;
         ipm = o;  o += r4(N * IPMW);
         dxv = o;  o += 48;
         duv = o;  o += 32;
@@ -370,11 +371,64 @@ struct WbLds {
     }
 };
 
+// Eight multipliers of pivot J at once: eight v_readlane into eight different SGPRs, then the wait states a VALU read of
+// a freshly written SGPR needs on gfx950 -- once per group.  Left to the compiler the elimination came out as
+// readlane -> s_nop 1 -> fma on ONE reused SGPR, 435 times per stage (tools/wb_stamps.py: 7.8 k cycles per stage).
+template <int J>
+__device__ __forceinline__ void bcast_group(const float (&v)[8], float (&o)[8]) {
+    int r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("v_readlane_b32 %0, %8, %16\n\tv_readlane_b32 %1, %9, %16\n\tv_readlane_b32 %2, %10, %16\n\t"
+                 "v_readlane_b32 %3, %11, %16\n\tv_readlane_b32 %4, %12, %16\n\tv_readlane_b32 %5, %13, %16\n\t"
+                 "v_readlane_b32 %6, %14, %16\n\tv_readlane_b32 %7, %15, %16\n\ts_nop 1"
+                 : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3), "=s"(r4), "=s"(r5), "=s"(r6), "=s"(r7)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "n"(J));
+    o[0] = __int_as_float(r0); o[1] = __int_as_float(r1); o[2] = __int_as_float(r2); o[3] = __int_as_float(r3);
+    o[4] = __int_as_float(r4); o[5] = __int_as_float(r5); o[6] = __int_as_float(r6); o[7] = __int_as_float(r7);
+}
+// rows J+1 .. NU-1 of the elimination step of pivot J, eight rows per group (the last group padded with row NU-1)
+template <int J>
+__device__ __forceinline__ void ldl_update(float (&X)[NU], float wx) {
+    constexpr int first = J + 1, n = NU - first;
+#pragma unroll
+    for (int g = 0; g < (n + 7) / 8; ++g) {
+        float v[8], l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = X[(first + 8 * g + u < NU) ? first + 8 * g + u : NU - 1];
+        bcast_group<J>(v, l);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (first + 8 * g + u < NU) X[first + 8 * g + u] = fmaf(-l[u], wx, X[first + 8 * g + u]);
+    }
+}
+template <int J>
+__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
+    if constexpr (J < NU) {
+        const float d = bcast(X[J], J);
+        ok = ok && (d > 0.0f);
+        const float rs = __builtin_amdgcn_rsqf(d);
+        X[J] *= rs;
+        if constexpr (J + 1 < NU) ldl_update<J>(X, X[J] * rs);
+        ldl_pivots<J + 1>(X, ok);
+    }
+}
+
 __device__ __forceinline__ bool n_tile_nonzero(int k, int j) { return !((k == 0 && j == 0) || (k == 1 && j == 0) || (k == 1 && j == 1)); }
 __device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 && j == 1); }
 
+// Diagnostic build (-DNMPC_WB_STAMPS, tools/wb_stamps.py): cycle counters of the segments of a backward stage and of
+// the phases, summed per wave and left in the first Js image of the problem.  The production kernel has no stamp.
+#ifdef NMPC_WB_STAMPS
+#define WB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); \
+                         st_acc[i] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WB_STAMP(i)
+#endif
+
 // QP + step of one SQP iteration: one problem per wavefront.
 __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
+#ifdef NMPC_WB_STAMPS
+    unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -392,7 +446,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     float* dX = arr + SA.dX;   float* dU = arr + SA.dU;
     float* dXp = arr + SA.dXp; float* dUp = arr + SA.dUp;
     float* sv = arr + SA.sv;   float* lv = arr + SA.lv;
-    float* colU = smem + L.colU; float* colX = smem + L.colX; float* hbuf = smem + L.hbuf;
+    float* colU = smem + L.colU; float* hbuf = smem + L.hbuf;
     float* recb = smem + L.recb; float* ipm = smem + L.ipm;
     float* dxv = smem + L.dxv;   float* duv = smem + L.duv;
     const float* recs = ws + wl.rec;
@@ -447,6 +501,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 store_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane, acc);
             }
     }
+    WB_STAMP(12);
     // cost, active rows, cold start of the interior point: s = max(-c, s_min), lam = mu0 / s
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
@@ -501,17 +556,69 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         }
     };
 
-    // per-lane constants of the tile synthesis
-    // input-cost diagonal (W_acc on a[6..17], W_cnt_f_reg on f) + reg, for the diagonal element this lane may hold
-    float rdiag[UT];
+    // per-lane constants of the tile synthesis: every element of N~ = A~ - I, B~, R~ and S~ is ONE LDS read at a
+    // precomputed index -- into the stage record (defect, momentum Jacobians, or one of its constant slots 0, dt, dt^2)
+    // or into the stage's row of barrier-modified input terms.  (Lane predicates instead of indices cost an SGPR pair
+    // per element and tile: the loop-invariant masks spilled 626 SGPRs into VGPR lanes.)
+    constexpr int NT = 6, BT = 5;
+    // non-zero tiles of N~: (0,1) (0,2) (1,2) (2,0) (2,1) (2,2) ; of B~: (0,0) (1,0) (1,1) (2,0) (2,1)
+    int nIdx[NT][4], bIdx[BT][4], rIdx[4], sIdx[UT][4];
+    float rdiag[UT][4];
+    {
+        constexpr int nt_i[NT] = {0, 0, 1, 2, 2, 2}, nt_j[NT] = {1, 2, 2, 0, 1, 2};
+        constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
 #pragma unroll
-    for (int i = 0; i < UT; ++i) {
-        const int uu = 16 * i + c;
-        float w = 0.0f;
-        if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
-        if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
-        rdiag[i] = (uu < NU) ? w + a.reg : 0.0f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * nt_i[t] + 4 * q4 + r, col = 16 * nt_j[t] + c;
+                int idx = R_ZERO;
+                if (row < 18 && col == row + 18) idx = R_DT;
+                if (col == HX && row < NX) idx = R_D + row;
+                if (row >= 39 && row < 42 && col >= 3 && col < 18) idx = R_HQ + (row - 39) * 16 + (col - 3);
+                nIdx[t][r] = idx;
+            }
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * bt_i[t] + 4 * q4 + r, uc = 16 * bt_j[t] + c;
+                int idx = R_ZERO;
+                if (uc < 18 && row == uc) idx = R_DT2;
+                if (uc < 18 && row == uc + 18) idx = R_DT;
+                if (uc >= WF && uc < NU) {
+                    const int f = uc - WF;
+                    if (row >= 36 && row < 39 && row - 36 == f % 3) idx = R_CDT + f / 3;
+                    if (row >= 39 && row < 42) idx = R_HF + (row - 39) * 12 + f;
+                }
+                bIdx[t][r] = idx;
+            }
+        // input-cost tile (1,1): the barrier block of the foot, and the diagonal W_acc / W_cnt_f_reg + reg of (0,0), (1,1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ur = 16 + 4 * q4 + r, uc = 16 + c;
+            int idx = IPMW - 1;                                  // a slot that holds zero
+            if (ur >= WF && ur < NU && uc >= WF && uc < NU) {
+                const int fr = ur - WF, fc = uc - WF;
+                if (fr / 3 == fc / 3) {
+                    const int ar = fr % 3, ac = fc % 3;
+                    const int sel = (ar == ac) ? ar : (ar + ac == 2) ? 3 : (ar + ac == 3) ? 4 : -1;
+                    if (sel >= 0) idx = IPM_RF + 5 * (fr / 3) + sel;
+                }
+            }
+            rIdx[r] = idx;
+#pragma unroll
+            for (int i = 0; i < UT; ++i) {
+                const int uu = 16 * i + 4 * q4 + r;
+                float w = 0.0f;
+                if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
+                if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
+                rdiag[i][r] = (uu == 16 * i + c && uu < NU) ? w + a.reg : 0.0f;
+                sIdx[i][r] = (c == HX - 32 && uu < NU) ? uu : IPMW - 1;      // S~: the input gradient rides in column HX
+            }
+        }
     }
+    if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
 
     bool qp_ok = true;
     for (int ii = 0; ii < n_sweeps; ++ii) {
@@ -526,7 +633,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // record of stage N-1 into the LDS; each stage prefetches the next one's (global -> registers -> LDS)
         {
             const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (size_t)(N - 1) * REC + (4 * lane < REC ? 4 * lane : 0));
-            *reinterpret_cast<f32x4*>(recb + ((N - 1) & 1) * 256 + 4 * lane) = v;
+            *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
         }
         wave_sync();
         for (int k = N - 1; k >= 0; --k) {
@@ -539,44 +646,26 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j < XT; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
-            const float* rk = recb + (k & 1) * 256;
+            const float* rk = recb;
             const float* ik = ipm + k * IPMW;
-            // ---- synthesise N~ = A~ - I and B~ tiles from the record
+            WB_STAMP(0);
+            // ---- synthesise N~ = A~ - I and B~ tiles from the record (one LDS read per element)
             f32x4 Nt[XT][XT], Bt[XT][UT];
+            {
+                constexpr int nt_i[NT] = {0, 0, 1, 2, 2, 2}, nt_j[NT] = {1, 2, 2, 0, 1, 2};
+                constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
+                Nt[0][0] = Nt[1][0] = Nt[1][1] = zero4();
+                Bt[0][1] = zero4();
 #pragma unroll
-            for (int i = 0; i < XT; ++i)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    if (!n_tile_nonzero(i, j)) { Nt[i][j] = zero4(); continue; }
+                    for (int r = 0; r < 4; ++r) Nt[nt_i[t]][nt_j[t]][r] = rk[nIdx[t][r]];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
-                        float v = 0.0f;
-                        if (row < 18 && col == row + 18) v = dt;
-                        if (col == HX && row < NX) v = rk[R_D + (row < NX ? row : 0)];
-                        if (row >= 39 && row < 42 && col >= 3 && col < 18) v = rk[R_HQ + ((row >= 39 && row < 42) ? row - 39 : 0) * 16 + ((col >= 3 && col < 18) ? col - 3 : 0)];
-                        Nt[i][j][r] = v;
-                    }
-                }
+                for (int t = 0; t < BT; ++t)
 #pragma unroll
-            for (int i = 0; i < XT; ++i)
-#pragma unroll
-                for (int j = 0; j < UT; ++j) {
-                    if (!b_tile_nonzero(i, j)) { Bt[i][j] = zero4(); continue; }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * q4 + r, uc = 16 * j + c;
-                        float v = 0.0f;
-                        if (uc < 18 && row == uc) v = dt * dt;
-                        if (uc < 18 && row == uc + 18) v = dt;
-                        if (uc >= WF && uc < NU) {
-                            const int f = uc - WF;
-                            if (row >= 36 && row < 39 && row - 36 == f % 3) v = rk[R_CDT + f / 3];
-                            if (row >= 39 && row < 42) v = rk[R_HF + (row - 39) * 12 + f];
-                        }
-                        Bt[i][j][r] = v;
-                    }
-                }
+                    for (int r = 0; r < 4; ++r) Bt[bt_i[t]][bt_j[t]][r] = rk[bIdx[t][r]];
+            }
+            WB_STAMP(1);
             // ---- P~A~ = P~ + P~N~ ,  P~B~
             f32x4 PA[XT][XT], PB[XT][UT];
 #pragma unroll
@@ -598,7 +687,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     PB[i][j] = acc;
                 }
             }
-            // ---- H~ux = S~ + B~'(P~A~) ,  Huu = R~ + B~'(P~B~)  -> LDS columns
+            WB_STAMP(2);
+            // ---- H~ux = S~ + B~'(P~A~) (stays in registers) ,  Huu = R~ + B~'(P~B~)  -> LDS columns
+            f32x4 Hux[UT][XT];
 #pragma unroll
             for (int i = 0; i < UT; ++i) {
 #pragma unroll
@@ -606,33 +697,20 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     f32x4 acc = zero4();
                     if (j == 2) {   // S~: the input gradient rides in column HX
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int uu = 16 * i + 4 * q4 + r;
-                            acc[r] = (c == HX - 32 && uu < NU) ? ik[uu < NU ? uu : 0] : 0.0f;
-                        }
+                        for (int r = 0; r < 4; ++r) acc[r] = ik[sIdx[i][r]];
                     }
 #pragma unroll
                     for (int kk = 0; kk < XT; ++kk)
                         if (b_tile_nonzero(kk, i)) acc = xty(Bt[kk][i], PA[kk][j], acc);
-                    *reinterpret_cast<f32x4*>(colX + (16 * j + c) * LDU + 16 * i + 4 * q4) = acc;
+                    Hux[i][j] = acc;
                 }
 #pragma unroll
                 for (int j = 0; j < UT; ++j) {
                     f32x4 acc = zero4();
                     {   // all four tiles: lane L > j of the elimination reads row j of column L (upper triangle)
+                        if (i == j) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int ur = 16 * i + 4 * q4 + r, uc = 16 * j + c;
-                            float v = (ur == uc) ? rdiag[j] : 0.0f;
-                            if (ur >= WF && ur < NU && uc >= WF && uc < NU) {       // barrier block of the foot
-                                const int fr = ur - WF, fc = uc - WF;
-                                if (fr / 3 == fc / 3) {
-                                    const int ar = fr % 3, ac = fc % 3, ft = fr / 3;
-                                    const int sel = (ar == ac) ? ar : (ar + ac == 2) ? 3 : (ar + ac == 3) ? 4 : -1;
-                                    if (sel >= 0) v += ik[IPM_RF + 5 * ft + sel];
-                                }
-                            }
-                            acc[r] = v;
+                            for (int r = 0; r < 4; ++r) acc[r] = rdiag[i][r] + (i == 1 ? ik[rIdx[r]] : 0.0f);
                         }
 #pragma unroll
                         for (int kk = 0; kk < XT; ++kk)
@@ -641,6 +719,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     *reinterpret_cast<f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4) = acc;
                 }
             }
+            WB_STAMP(3);
             // ---- H = Q~ + P~A~ + N~'(P~A~) ; H~xx = (H + H')/2 through the LDS
             f32x4 H[XT][XT];
 #pragma unroll
@@ -654,55 +733,34 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     H[i][j] = acc;
                     *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = acc;
                 }
-            // next stage's record goes to the other LDS buffer
-            *reinterpret_cast<f32x4*>(recb + (kn & 1) * 256 + 4 * lane) = rec_next;
+            // next stage's record replaces this one's (all of its reads are issued above)
+            *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_next;
             wave_sync();
-#ifdef NMPC_WB_DEBUG   // bring-up build (tools/wb_debug.py): the elimination's input and output of stage N-1
-            if (k == N - 1) {
-                float* dbg = ws + wl.js;
-                for (int i = lane; i < 32 * LDU; i += 64) dbg[i] = colU[i];
-                for (int i = lane; i < 48 * LDU; i += 64) dbg[32 * LDU + i] = colX[i];
-                for (int i = lane; i < 48 * LDH; i += 64) dbg[80 * LDU + i] = hbuf[i];
-            }
-#endif
-            // ---- LDL' of Huu in column layout applied to [H~ux | I]
-            // lanes 0..31: column `lane` of Huu; lanes 32..63: column lane-32 of I; every lane: column `lane` of H~ux
-            float Xc[NU], Cc[NU];
+            WB_STAMP(4);
+            // ---- LDL' of Huu in column layout applied to the identity: W = D^-1/2 L^-1
+            // lanes 0..31: column `lane` of Huu; lanes 32..63: column lane-32 of I.  One broadcast and one FMA per
+            // multiplier; the right-hand side H~ux is NOT carried through the elimination (the compiler split a second
+            // column per lane into a pass of its own and parked all 435 multipliers in spilled SGPRs for it): Y = W H~ux
+            // is formed on the matrix pipe below.
+            float Xc[NU];
             {
                 const bool is_h = lane < 32;
                 const float* pu = colU + (is_h ? lane : 0) * LDU;
-                const float* px = colX + (lane < 48 ? lane : 47) * LDU;
 #pragma unroll
                 for (int i4 = 0; i4 < 8; ++i4) {
                     const f32x4 vu = *reinterpret_cast<const f32x4*>(pu + 4 * i4);
-                    const f32x4 vx = *reinterpret_cast<const f32x4*>(px + 4 * i4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * i4 + r;
-                        if (i < NU) {
-                            Xc[i] = is_h ? vu[r] : ((lane - 32 == i) ? 1.0f : 0.0f);
-                            Cc[i] = vx[r];
-                        }
+                        if (i < NU) Xc[i] = is_h ? vu[r] : ((lane - 32 == i) ? 1.0f : 0.0f);
                     }
                 }
             }
             bool ok = true;
-#pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                const float d = bcast(Xc[j], j);
-                ok = ok && (d > 0.0f);
-                const float rs = __builtin_amdgcn_rsqf(d);
-                Xc[j] *= rs; Cc[j] *= rs;
-                const float wx = Xc[j] * rs, wc = Cc[j] * rs;
-#pragma unroll
-                for (int i = j + 1; i < NU; ++i) {
-                    const float l = bcast(Xc[i], j);
-                    Xc[i] = fmaf(-l, wx, Xc[i]);
-                    Cc[i] = fmaf(-l, wc, Cc[i]);
-                }
-            }
+            ldl_pivots<0>(Xc, ok);
             qp_ok = qp_ok && ok;
-            // transposed H for the symmetrisation (reads issued before the columns are overwritten: other buffer)
+            WB_STAMP(5);
+            // transposed H for the symmetrisation
             f32x4 Ht[XT][XT];
 #pragma unroll
             for (int i = 0; i < XT; ++i)
@@ -712,40 +770,45 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     Ht[i][j] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
                 }
             wave_sync();
-            // write back: W (lanes 32..63 -> colU column lane-32), Y (lanes 0..47 -> colX column lane)
+            // W columns back into the LDS (lanes 32..63 -> column lane-32), then as tiles: W and W'
             {
                 float* pw = colU + (lane >= 32 ? lane - 32 : 0) * LDU;
-                float* py = colX + (lane < 48 ? lane : 47) * LDU;
 #pragma unroll
                 for (int i4 = 0; i4 < 8; ++i4) {
-                    f32x4 vw, vy;
+                    f32x4 vw;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * i4 + r;
                         vw[r] = (i < NU) ? Xc[i < NU ? i : 0] : 0.0f;
-                        vy[r] = (i < NU) ? Cc[i < NU ? i : 0] : 0.0f;
                     }
                     if (lane >= 32) *reinterpret_cast<f32x4*>(pw + 4 * i4) = vw;
-                    if (lane < 48) *reinterpret_cast<f32x4*>(py + 4 * i4) = vy;
                 }
             }
             wave_sync();
-#ifdef NMPC_WB_DEBUG
-            if (k == N - 1) {
-                float* dbg = ws + wl.js + 80 * LDU + 48 * LDH;
-                for (int i = lane; i < 32 * LDU; i += 64) dbg[i] = colU[i];
-                for (int i = lane; i < 48 * LDU; i += 64) dbg[32 * LDU + i] = colX[i];
-            }
-#endif
-            f32x4 Y[UT][XT], Wt[UT][UT];
+            f32x4 Wt[UT][UT], WT[UT][UT];      // W[i][j] (rows 16i.., columns 16j..) and its transpose W'[j][i] = WT[i][j]
 #pragma unroll
-            for (int i = 0; i < UT; ++i) {
+            for (int i = 0; i < UT; ++i)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) Y[i][j] = *reinterpret_cast<const f32x4*>(colX + (16 * j + c) * LDU + 16 * i + 4 * q4);
-#pragma unroll
-                for (int j = 0; j < UT; ++j) Wt[i][j] = *reinterpret_cast<const f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4);
-            }
+                for (int j = 0; j <= i; ++j) {
+                    Wt[i][j] = *reinterpret_cast<const f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4);
+                    const float* pt = colU + (16 * j + 4 * q4) * LDU + 16 * i + c;      // element (4q+r, c) of W[i][j]' = W[16i+c][16j+4q+r]
+                    WT[i][j] = f32x4{pt[0], pt[LDU], pt[2 * LDU], pt[3 * LDU]};
+                }
+            Wt[0][1] = zero4();
             wave_sync();
+            WB_STAMP(6);
+            // Y = W H~ux:  Y[i][j] = sum_{kk <= i} W[i][kk] H~ux[kk][j] = sum xty(W[i][kk]', H~ux[kk][j])
+            f32x4 Y[UT][XT];
+#pragma unroll
+            for (int i = 0; i < UT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int kk = 0; kk <= i; ++kk) acc = xty(WT[i][kk], Hux[kk][j], acc);
+                    Y[i][j] = acc;
+                }
+            WB_STAMP(7);
             // ---- P~+ = H~xx - Y'Y ,  K~ = -W'Y
 #pragma unroll
             for (int i = 0; i < XT; ++i)
@@ -771,6 +834,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, acc);
                 }
         }
+        WB_STAMP(8);
         phase_sync();
         // ------------------------------------------------------------ phase F: forward sweep
         float* oX = use_ipm ? dXp : dX;
@@ -788,24 +852,33 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
         }
         wave_sync();
-        // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16)
+        // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16).  The row of the next stage is
+        // requested before this stage's is used (a stage is far shorter than a trip to the L2 / HBM: unprefetched, the
+        // forward sweep cost 6.9 k cycles per stage against 27 k for the backward stage).
         const int urow = lane < NU ? lane : 0;
         const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
-        for (int k = 0; k < N; ++k) {
+        auto load_krow = [&](int k, float (&row)[HX + 1]) {
             const float* Kk = Kimg + (size_t)k * KT_FLOATS + krow_off;
+#pragma unroll
+            for (int j = 0; j <= HX; ++j) row[j] = Kk[(j >> 4) * IMG + (j & 15) * TS];
+        };
+        auto fwd_stage = [&](int k, const float (&row)[HX + 1], float (&row_next)[HX + 1]) {
             const int kn = k + 1 < N ? k + 1 : k;
+            load_krow(kn, row_next);
             const f32x4 rec_next = *reinterpret_cast<const f32x4*>(recs + (size_t)kn * REC + (4 * lane < REC ? 4 * lane : 0));
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
-            for (int j = 0; j <= HX; ++j) {
-                const float e = Kk[(j >> 4) * IMG + (j & 15) * TS];
-                float& ac = (j & 3) == 0 ? a0 : (j & 3) == 1 ? a1 : (j & 3) == 2 ? a2 : a3;
-                ac = fmaf(e, dxv[j], ac);
+            for (int j4 = 0; j4 < 11; ++j4) {
+                const f32x4 dx = *reinterpret_cast<const f32x4*>(dxv + 4 * j4);      // broadcast read
+                a0 = fmaf(row[4 * j4], dx[0], a0);
+                a1 = fmaf(row[4 * j4 + 1], dx[1], a1);
+                a2 = fmaf(row[4 * j4 + 2], dx[2], a2);
+                if (4 * j4 + 3 <= HX) a3 = fmaf(row[(4 * j4 + 3 <= HX) ? 4 * j4 + 3 : 0], dx[3], a3);
             }
             const float du = (a0 + a1) + (a2 + a3);
             if (lane < NU) { duv[lane] = du; AT(oU, k, lane) = du; }
             wave_sync();
-            const float* rk = recb + (k & 1) * 256;
+            const float* rk = recb;
             float xn = 0.0f;
             if (lane < NX) {
                 const int i = lane;
@@ -826,10 +899,21 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             wave_sync();
             if (lane < NX) { dxv[lane] = xn; AT(oX, k + 1, lane) = xn; }
-            *reinterpret_cast<f32x4*>(recb + (kn & 1) * 256 + 4 * lane) = rec_next;
+            *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_next;
             wave_sync();
+        };
+        {
+            float rowA[HX + 1], rowB[HX + 1];
+            load_krow(0, rowA);
+            int k = 0;
+            for (; k + 2 <= N; k += 2) {
+                fwd_stage(k, rowA, rowB);
+                fwd_stage(k + 1, rowB, rowA);
+            }
+            if (k < N) fwd_stage(k, rowA, rowB);
         }
         phase_sync();
+        WB_STAMP(9);
         // ------------------------------------------------------------ phase I: interior-point update, lane = stage
         if (use_ipm) {
             const bool live = lane < N;
@@ -874,6 +958,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
         }
     }
+    WB_STAMP(10);
     // ---------------------------------------------------------------- phase S: step
     float sn_l = 0.0f;
     bool bad_l = false;
@@ -929,6 +1014,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             if (a.shift > 0) phase_sync();
         }
     }
+#ifdef NMPC_WB_STAMPS
+    WB_STAMP(11);
+    if (lane == 0) for (int i = 0; i < 16; ++i) (ws + wl.js)[i] = (float)st_acc[i];
+#endif
     if (lane == 0) {
         flag[0] = finished ? 1 : 0;
         if (a.status) a.status[b] = status;
