@@ -386,9 +386,9 @@ __device__ __forceinline__ void bcast_group(const float (&v)[8], float (&o)[8]) 
     o[4] = __int_as_float(r4); o[5] = __int_as_float(r5); o[6] = __int_as_float(r6); o[7] = __int_as_float(r7);
 }
 // rows J+1 .. NU-1 of the elimination step of pivot J, eight rows per group (the last group padded with row NU-1)
-template <int J>
+template <int J, int FIRST>
 __device__ __forceinline__ void ldl_update(float (&X)[NU], float wx) {
-    constexpr int first = J + 1, n = NU - first;
+    constexpr int first = FIRST, n = NU - first;
 #pragma unroll
     for (int g = 0; g < (n + 7) / 8; ++g) {
         float v[8], l[8];
@@ -400,15 +400,19 @@ __device__ __forceinline__ void ldl_update(float (&X)[NU], float wx) {
             if (first + 8 * g + u < NU) X[first + 8 * g + u] = fmaf(-l[u], wx, X[first + 8 * g + u]);
     }
 }
+// Pivot J with 1/sqrt(d_J) in hand.  Row J+1 is updated first and the next pivot's broadcast + v_rsq are issued right
+// behind it, so that their latency runs under the updates of the rows J+2.. instead of in front of the next pivot.
 template <int J>
-__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
-    if constexpr (J < NU) {
-        const float d = bcast(X[J], J);
-        ok = ok && (d > 0.0f);
-        const float rs = __builtin_amdgcn_rsqf(d);
-        X[J] *= rs;
-        if constexpr (J + 1 < NU) ldl_update<J>(X, X[J] * rs);
-        ldl_pivots<J + 1>(X, ok);
+__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok, float rs) {
+    X[J] *= rs;
+    if constexpr (J + 1 < NU) {
+        const float wx = X[J] * rs;
+        X[J + 1] = fmaf(-bcast(X[J + 1], J), wx, X[J + 1]);
+        const float d1 = bcast(X[J + 1], J + 1);
+        ok = ok && (d1 > 0.0f);
+        const float rs1 = __builtin_amdgcn_rsqf(d1);
+        if constexpr (J + 2 < NU) ldl_update<J, J + 2>(X, wx);
+        ldl_pivots<J + 1>(X, ok, rs1);
     }
 }
 
@@ -462,6 +466,14 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 
     // ---------------------------------------------------------------- prologue: Q~_k = Js'Js + diag (+ gradient)
     // the Gauss-Newton contraction J'WJ of the dense residual rows on the matrix pipe
+    float qdiag[XT], qdiag_e[XT];      // diagonal element this lane may hold in tile (I, I): weight + reg
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        const int row = 16 * i + c;
+        const bool mine = (c >> 2) == q4 && row < NX;
+        qdiag[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, false) : 0.0f) + a.reg : 0.0f;
+        qdiag_e[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, true) : 0.0f) + a.reg_e : 0.0f;
+    }
     for (int k = 0; k <= N; ++k) {
         const bool term = (k == N);
         const float* js = ws + wl.js + (size_t)k * JS_FLOATS;
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
                     float v = acc[r];
-                    if (row == col && row < NX) v += (row < 36 ? wdiag(a, row < 36 ? row : 0, term) : 0.0f) + (term ? a.reg_e : a.reg);
+                    if (i == j && r == (c & 3)) v += term ? qdiag_e[i] : qdiag[i];      // row == col <=> r == c - 4q
                     if (col == HX && row < 36) v += gcol[i][r];
                     if (row == HX && col < 36) v += grow[j];
                     if (row == HX && col == HX) v = 0.0f;
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
+                for (int j = 0; j <= i; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
             const float* rk = recb;
             const float* ik = ipm + k * IPMW;
             WB_STAMP(0);
@@ -689,50 +701,68 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             WB_STAMP(2);
             // ---- H~ux = S~ + B~'(P~A~) (stays in registers) ,  Huu = R~ + B~'(P~B~)  -> LDS columns
-            f32x4 Hux[UT][XT];
+            // (products are written step by step over several output tiles at once: a dependent fp32 MFMA waits 40
+            //  cycles for its accumulator, an independent one issues after 32 -- tools/wb_stamps.py)
+            f32x4 Hux[UT][XT], Huu[UT][UT];
 #pragma unroll
             for (int i = 0; i < UT; ++i) {
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
-                    f32x4 acc = zero4();
+                    Hux[i][j] = zero4();
                     if (j == 2) {   // S~: the input gradient rides in column HX
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[r] = ik[sIdx[i][r]];
+                        for (int r = 0; r < 4; ++r) Hux[i][j][r] = ik[sIdx[i][r]];
                     }
-#pragma unroll
-                    for (int kk = 0; kk < XT; ++kk)
-                        if (b_tile_nonzero(kk, i)) acc = xty(Bt[kk][i], PA[kk][j], acc);
-                    Hux[i][j] = acc;
                 }
 #pragma unroll
-                for (int j = 0; j < UT; ++j) {
-                    f32x4 acc = zero4();
-                    {   // all four tiles: lane L > j of the elimination reads row j of column L (upper triangle)
-                        if (i == j) {
+                for (int j = 0; j <= i; ++j) {
+                    Huu[i][j] = zero4();
+                    if (i == j) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[r] = rdiag[i][r] + (i == 1 ? ik[rIdx[r]] : 0.0f);
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < XT; ++kk)
-                            if (b_tile_nonzero(kk, i)) acc = xty(Bt[kk][i], PB[kk][j], acc);
+                        for (int r = 0; r < 4; ++r) Huu[i][j][r] = rdiag[i][r] + (i == 1 ? ik[rIdx[r]] : 0.0f);
                     }
-                    *reinterpret_cast<f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4) = acc;
+                }
+#pragma unroll
+                for (int kk = 0; kk < XT; ++kk)
+                    if (b_tile_nonzero(kk, i)) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                            for (int j = 0; j < XT; ++j) Hux[i][j] = mfma4(Bt[kk][i][st], PA[kk][j][st], Hux[i][j]);
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) Huu[i][j] = mfma4(Bt[kk][i][st], PB[kk][j][st], Huu[i][j]);
+                        }
+                    }
+                // lower tiles only; lane L > j of the elimination reads row j of column L (upper triangle), so the
+                // off-diagonal tile is written a second time, transposed, into the (0,1) position
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    *reinterpret_cast<f32x4*>(colU + (16 * j + c) * LDU + 16 * i + 4 * q4) = Huu[i][j];
+                    if (i != j) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) colU[(16 * i + 4 * q4 + r) * LDU + 16 * j + c] = Huu[i][j][r];
+                    }
                 }
             }
             WB_STAMP(3);
-            // ---- H = Q~ + P~A~ + N~'(P~A~) ; H~xx = (H + H')/2 through the LDS
+            // ---- H = Q~ + P~A~ + N~'(P~A~), lower tiles only; the upper ones and the symmetrisation of the diagonal
+            // tiles come back transposed from the LDS: H~xx is symmetric bit for bit
             f32x4 H[XT][XT];
 #pragma unroll
-            for (int i = 0; i < XT; ++i)
+            for (int i = 0; i < XT; ++i) {
 #pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    f32x4 acc = Q[i][j] + PA[i][j];
+                for (int j = 0; j <= i; ++j) H[i][j] = Q[i][j] + PA[i][j];
 #pragma unroll
-                    for (int kk = 0; kk < XT; ++kk)
-                        if (n_tile_nonzero(kk, i)) acc = xty(Nt[kk][i], PA[kk][j], acc);
-                    H[i][j] = acc;
-                    *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = acc;
-                }
+                for (int kk = 0; kk < XT; ++kk)
+                    if (n_tile_nonzero(kk, i)) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st)
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) H[i][j] = mfma4(Nt[kk][i][st], PA[kk][j][st], H[i][j]);
+                    }
+#pragma unroll
+                for (int j = 0; j <= i; ++j) *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = H[i][j];
+            }
             // next stage's record replaces this one's (all of its reads are issued above)
             *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_next;
             wave_sync();
@@ -756,17 +786,18 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     }
                 }
             }
-            bool ok = true;
-            ldl_pivots<0>(Xc, ok);
+            const float d0 = bcast(Xc[0], 0);
+            bool ok = d0 > 0.0f;
+            ldl_pivots<0>(Xc, ok, __builtin_amdgcn_rsqf(d0));
             qp_ok = qp_ok && ok;
             WB_STAMP(5);
-            // transposed H for the symmetrisation
+            // transposed tiles: Ht[i][j] = (lower tile (i,j))', i >= j
             f32x4 Ht[XT][XT];
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    const float* ph = hbuf + (16 * i + 4 * q4) * LDH + 16 * j + c;
+                for (int j = 0; j <= i; ++j) {
+                    const float* ph = hbuf + (16 * j + 4 * q4) * LDH + 16 * i + c;      // element (4q+r, c) of the transpose = H[16i+c][16j+4q+r]
                     Ht[i][j] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
                 }
             wave_sync();
@@ -802,37 +833,71 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int i = 0; i < UT; ++i)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    f32x4 acc = zero4();
+                for (int j = 0; j < XT; ++j) Y[i][j] = zero4();
 #pragma unroll
-                    for (int kk = 0; kk <= i; ++kk) acc = xty(WT[i][kk], Hux[kk][j], acc);
-                    Y[i][j] = acc;
-                }
+            for (int kk = 0; kk < UT; ++kk)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int i = kk; i < UT; ++i)
+#pragma unroll
+                        for (int j = 0; j < XT; ++j) Y[i][j] = mfma4(WT[i][kk][st], Hux[kk][j][st], Y[i][j]);
             WB_STAMP(7);
-            // ---- P~+ = H~xx - Y'Y ,  K~ = -W'Y
-#pragma unroll
-            for (int i = 0; i < XT; ++i)
-#pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    f32x4 acc = 0.5f * (H[i][j] + Ht[i][j]);
-#pragma unroll
-                    for (int kk = 0; kk < UT; ++kk) acc = xty(-Y[kk][i], Y[kk][j], acc);
-                    if (i == 2 && j == 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (c == HX - 32 && 32 + 4 * q4 + r == HX) acc[r] = 0.0f;
-                    }
-                    P[i][j] = acc;
-                }
+            // ---- P~+ = H~xx - Y'Y (lower tiles; the upper ones are their transposes through the LDS) ,  K~ = -W'Y
+            f32x4 nY[UT][XT];
 #pragma unroll
             for (int i = 0; i < UT; ++i)
 #pragma unroll
-                for (int j = 0; j < XT; ++j) {
-                    f32x4 acc = zero4();
+                for (int j = 0; j < XT; ++j) nY[i][j] = -Y[i][j];
 #pragma unroll
-                    for (int kk = i; kk < UT; ++kk) acc = xty(-Wt[kk][i], Y[kk][j], acc);   // W is lower triangular
-                    store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, acc);
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) P[i][j] = (i == j) ? 0.5f * (H[i][j] + Ht[i][j]) : H[i][j];
+#pragma unroll
+            for (int kk = 0; kk < UT; ++kk)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int i = 0; i < XT; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) P[i][j] = mfma4(nY[kk][i][st], Y[kk][j][st], P[i][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c == HX - 32 && 32 + 4 * q4 + r == HX) P[2][2][r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < i; ++j) *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = P[i][j];
+            WB_STAMP(13);
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < i; ++j) {
+                    const float* ph = hbuf + (16 * j + 4 * q4) * LDH + 16 * i + c;
+                    P[j][i] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
                 }
+            WB_STAMP(14);
+            {
+                f32x4 Kt[UT][XT];
+#pragma unroll
+                for (int i = 0; i < UT; ++i)
+#pragma unroll
+                    for (int j = 0; j < XT; ++j) Kt[i][j] = zero4();
+#pragma unroll
+                for (int kk = 0; kk < UT; ++kk)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int i = 0; i <= kk; ++i)                                   // W is lower triangular
+#pragma unroll
+                            for (int j = 0; j < XT; ++j) Kt[i][j] = mfma4(Wt[kk][i][st], nY[kk][j][st], Kt[i][j]);
+#pragma unroll
+                for (int i = 0; i < UT; ++i)
+#pragma unroll
+                    for (int j = 0; j < XT; ++j) store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
+            }
+            WB_STAMP(15);
         }
         WB_STAMP(8);
         phase_sync();
@@ -880,22 +945,46 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             wave_sync();
             const float* rk = recb;
             float xn = 0.0f;
-            if (lane < NX) {
-                const int i = lane;
+            {
+                const int i = lane < NX ? lane : 0;
                 xn = dxv[i] + rk[R_D + i];
-                if (i < 18) xn += dt * dxv[i + 18] + dt * dt * duv[i];
-                else if (i < 36) xn += dt * duv[i - 18];
-                else if (i < 39) {
+                // kinematic rows: one or two terms at lane-dependent places (clamped, selected)
+                const float t_q = dt * dxv[i < 18 ? i + 18 : 0] + dt * dt * duv[i < 18 ? i : 0];
+                const float t_v = dt * duv[(i >= 18 && i < 36) ? i - 18 : 0];
+                xn += (i < 18) ? t_q : (i < 36) ? t_v : 0.0f;
+                // momentum rows 36..41 (every lane runs the code on a clamped row; six lanes keep the result):
+                // linear rows: sum_f cdt_f duf[3f + i-36]; angular rows: Hq[i-39] . dx[3..17] + Hf[i-39] . duf
+                const int hr = (i >= 39) ? i - 39 : 0, lr = (i >= 36 && i < 39) ? i - 36 : 0;
+                float acc_a = 0.0f, acc_l = 0.0f;
+                const f32x4* hq4 = reinterpret_cast<const f32x4*>(rk + R_HQ + hr * 16);
+                const f32x4* hf4 = reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12);
+                const f32x4* dx4 = reinterpret_cast<const f32x4*>(dxv);
+                const f32x4* du4 = reinterpret_cast<const f32x4*>(duv);
+                float dxs[20], dus[16];
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) xn += rk[R_CDT + f] * duv[WF + 3 * f + (i - 36)];
-                } else {
-                    const float* hq = rk + R_HQ + (i - 39) * 16;
-                    const float* hf = rk + R_HF + (i - 39) * 12;
+                for (int v4 = 0; v4 < 5; ++v4) { const f32x4 t4 = dx4[v4]; dxs[4 * v4] = t4[0]; dxs[4 * v4 + 1] = t4[1]; dxs[4 * v4 + 2] = t4[2]; dxs[4 * v4 + 3] = t4[3]; }
 #pragma unroll
-                    for (int cc = 0; cc < 15; ++cc) xn += hq[cc] * dxv[3 + cc];
+                for (int v4 = 0; v4 < 4; ++v4) { const f32x4 t4 = du4[4 + v4]; dus[4 * v4] = t4[0]; dus[4 * v4 + 1] = t4[1]; dus[4 * v4 + 2] = t4[2]; dus[4 * v4 + 3] = t4[3]; }
 #pragma unroll
-                    for (int f = 0; f < 12; ++f) xn += hf[f] * duv[WF + f];
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const f32x4 h4 = hq4[v4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * v4 + r < 15) acc_a = fmaf(h4[r], dxs[3 + 4 * v4 + r], acc_a);
                 }
+#pragma unroll
+                for (int v4 = 0; v4 < 3; ++v4) {
+                    const f32x4 h4 = hf4[v4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc_a = fmaf(h4[r], dus[2 + 4 * v4 + r], acc_a);      // duf[f] = duv[18 + f]
+                }
+                const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const float sel = lr == 0 ? dus[2 + 3 * f] : lr == 1 ? dus[3 + 3 * f] : dus[4 + 3 * f];
+                    acc_l = fmaf(cd[f], sel, acc_l);
+                }
+                xn += (i >= 39) ? acc_a : (i >= 36) ? acc_l : 0.0f;
             }
             wave_sync();
             if (lane < NX) { dxv[lane] = xn; AT(oX, k + 1, lane) = xn; }
