@@ -372,8 +372,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default 1024 centroidal, 8192 whole-body)")
     ap.add_argument("--ipm", type=int, default=6)
     ap.add_argument("--sqp", type=int, default=1)
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 1),
-                    help="0: fp32 (headline); 1: bf16 barrier product, BASELINE configs[4] (a different config, not the headline)")
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 1, 2),
+                    help="0: fp32 (headline); BASELINE configs[4], mixed precision (a different config, not the headline): 1 = the "
+                         "Gauss-Newton contraction on the bf16 matrix pipe, 2 = split bf16 (whole-body only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-start", action="store_true", help="leave out the 15-iteration cold-start variant (profiling runs)")
     ap.add_argument("--rollouts", type=int, default=0,
@@ -415,7 +416,6 @@ def main():
     wbm = a.workload == "wholebody"
     B, N = (a.batch or (8192 if wbm else 1024)), (30 if wbm else 50)
     if wbm:
-        assert a.precision == 0, "the whole-body model runs in fp32"
         if a.steps == 200 and a.warmup == 20:      # defaults sized for the 0.5 ms centroidal step
             a.steps, a.warmup = 20, 3
     w = wl.wholebody_trot(B=B, N=N, seed=1000 * rank) if wbm else wl.centroidal_trot(B=B, N=N, seed=1000 * rank)
@@ -529,8 +529,9 @@ def main():
             "value": world * B * a.steps / elapsed, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if a.precision == 0 else "f32 (bf16 barrier product)", "data": "synthetic",
-            "config": {"workload": (f"configs[2]: batch={B}/GPU whole-body 18-DoF quadruped NMPC nx=42 nu=30 N=30 fp32, friction-pyramid + "
+            "vs_baseline": None, "dtype": "f32" if a.precision == 0 else ("f32 (bf16 J'WJ contraction)" if a.precision == 1 else "f32 (split-bf16 J'WJ contraction)"), "data": "synthetic",
+            "config": {"workload": (f"configs[{2 if a.precision == 0 else 4}]: batch={B}/GPU whole-body 18-DoF quadruped NMPC nx=42 nu=30 N=30 "
+                                    f"{'fp32' if a.precision == 0 else 'mixed precision (bf16 Jacobian, MFMA J^T W J, fp32 Riccati)'}, friction-pyramid + "
                                     f"stance constraints, {a.sqp} SQP x {a.ipm} IPM Riccati sweeps per solve, warm-start shift + solve per step") if wbm else
                                    (f"configs[{1 if a.precision == 0 else 4}]: batch={B}/GPU centroidal quadruped NMPC nx=12 nu=12 N=50 "
                                     f"{'fp32' if a.precision == 0 else 'mixed precision (bf16 MFMA barrier product, fp32 Riccati)'}, "

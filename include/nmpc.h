@@ -80,9 +80,14 @@ typedef struct {
     int model_id;  /* NMPC_MODEL_*                                             */
     int N;         /* horizon (number of shooting intervals)                  */
     int B_max;     /* largest batch a *_batch call will be given              */
-    int precision; /* 0 = fp32; 1 = mixed: the interior-point barrier product  */
-                   /* G'DG | G'v (the J'WJ contraction of the QP) in bf16 on   */
-                   /* the matrix pipe, everything else fp32 (BASELINE cfg 5)   */
+    int precision; /* 0 = fp32.  Mixed precision (BASELINE configs[4]: bf16 Jacobian,  */
+                   /* J'WJ on the bf16 matrix pipe, fp32 Riccati):                     */
+                   /* 1 = the Gauss-Newton contraction in bf16 with fp32 accumulation  */
+                   /*     -- whole-body: Q~ = Js'Js of the dense residual Jacobian;    */
+                   /*     centroidal: the barrier product G'DG | G'v (the only dense   */
+                   /*     contraction that model has) --, everything else fp32;        */
+                   /* 2 = whole-body only: split bf16, Js = hi + lo, three products.   */
+                   /* Measured deviations: DESIGN.md 7 (1: ~1e-3, 2: ~1e-5 level).     */
 } nmpc_dims;
 
 /* Dimensions of a model.  Any out pointer may be NULL. */

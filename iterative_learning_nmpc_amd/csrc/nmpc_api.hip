@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 
+#include "nmpc_device_guard.hpp"
 #include "nmpc_solve.hip"
 #include "nmpc_wb.hip"
 #include "nmpc_aux.hip.inc"
@@ -83,6 +84,7 @@ nmpc::wb::WbArgs wb_args(const Handle* h) {
     a.reg = h->reg; a.reg_e = h->reg_e;
     a.N = h->dims.N;
     a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm;
+    a.precision = h->dims.precision;
     a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
     a.gamma = h->gamma; a.tau_min = h->tau_min;
     a.ws = h->ws;
@@ -222,18 +224,17 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     int nx, nu, np, ng;
     if (nmpc_model_dims(dims->model_id, &nx, &nu, &np, &ng)) return fail(nullptr, NMPC_E_ARG, "unknown model_id");
     if (dims->N < 1 || dims->B_max < 1) return fail(nullptr, NMPC_E_ARG, "N and B_max must be positive");
-    if (dims->precision != 0 && dims->precision != 1)
-        return fail(nullptr, NMPC_E_ARG, "precision must be 0 (fp32) or 1 (bf16 barrier product)");
+    if (dims->precision < 0 || dims->precision > 2 || (dims->precision == 2 && dims->model_id != NMPC_MODEL_WHOLEBODY))
+        return fail(nullptr, NMPC_E_ARG, "precision must be 0 (fp32), 1 (bf16 contraction) or, whole-body only, 2 (split bf16)");
     Handle* h = new Handle();
     h->dims = *dims;
     h->device = device_id;
     h->nx = nx; h->nu = nu; h->np = np; h->ng = ng;
     nmpc_model_output_dims(dims->model_id, &h->ny, &h->nye);
-    if (dims->model_id == NMPC_MODEL_WHOLEBODY && dims->precision != 0)
-        { delete h; return fail(nullptr, NMPC_E_ARG, "the whole-body model runs in fp32 only"); }
     if (dims->model_id == NMPC_MODEL_WHOLEBODY && dims->N > 64)
         { delete h; return fail(nullptr, NMPC_E_ARG, "the whole-body model needs N <= 64 (lane = stage phases)"); }
-    hipError_t e = hipSetDevice(device_id);
+    nmpc::DeviceGuard guard(device_id);
+    hipError_t e = guard.err;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
     if (const char* v = std::getenv("NMPC_QP_VARIANT")) {
         if (!std::strcmp(v, "resident")) h->force_variant = 1;
@@ -265,7 +266,7 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
 void nmpc_destroy(void* handle) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    nmpc::DeviceGuard guard(h->device);
     if (h->ws) (void)hipFree(h->ws);
     if (h->roll) (void)hipFree(h->roll);
     delete h;
@@ -353,7 +354,8 @@ int nmpc_shift_warm_start(void* handle, int B, int shift, float* X, float* U, vo
     if (shift > N) shift = N;
     if ((size_t)N * h->nx > 256 * 16 || (size_t)N * h->nu > 256 * 16)
         return fail(h, NMPC_E_ARG, "trajectory too long for the shift kernel");
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     hipLaunchKernelGGL(nmpc::nmpc_shift_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
                        N, h->nx, h->nu, shift, X, U);
     HIP_TRY(h, hipGetLastError());
@@ -371,7 +373,8 @@ int nmpc_shift_solve_batch(void* handle, int B, int shift, const float* x0, cons
     if (shift < 0) return fail(h, NMPC_E_ARG, "negative shift");
     if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     if (h->ws_dirty) {
         HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
         h->ws_dirty = false;
@@ -412,7 +415,8 @@ int nmpc_riccati_batch(void* handle, int Bsz, int nx, int nu, const float* Q, co
     if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) return fail(h, NMPC_E_ARG, "nmpc_riccati_batch needs a handle of the tile-family models");
     if (Bsz < 0 || Bsz > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
     if (Bsz == 0) return NMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     nmpc::RiccatiArgs a{h->dims.N, Bsz, nx, nu, Q, R, q, r, A, B_, d, dx0, dX, dU, status, h->ws};
     h->ws_dirty = true;
     hipLaunchKernelGGL(nmpc::nmpc_riccati_kernel, dim3(Bsz), dim3(64), 0, static_cast<hipStream_t>(stream), a);
@@ -428,6 +432,7 @@ int nmpc_tracking_error(void* handle, int B, int T, int ns, const float* S, cons
     if (B < 0 || T < 1 || ns < 2) return fail(h, NMPC_E_ARG, "need B >= 0, T >= 1, ns >= 2");
     const size_t lds = (size_t)nmpc::TRB * (ns | 1) * sizeof(float);
     if (lds > 64 * 1024) return fail(h, NMPC_E_ARG, "state dimension too large for the staging tile");
+    nmpc::DeviceGuard guard(nmpc::device_of(S));
     const long long rows = (long long)B * T;
     const long long blocks = (rows + nmpc::TRB - 1) / nmpc::TRB;
     if (blocks > 0x7fffffffLL) return fail(h, NMPC_E_ARG, "too many rows");
@@ -459,7 +464,8 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         std::fabs(cfg->nodes_per_replan * (cfg->time_horizon / h->dims.N) - cfg->replanning_steps * cfg->sim_dt) > 1e-9)
         return fail(h, NMPC_E_ARG, "per-step recording needs nodes_per_replan * dt_nodes = replanning_steps * sim_dt");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     if (h->ws_dirty) {
         HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
         h->ws_dirty = false;
@@ -524,7 +530,8 @@ int nmpc_debug_read_tile(void* handle, int b, int k, int which, float* out_host)
     if (!h || !out_host) return fail(h, NMPC_E_ARG, "null argument");
     if (b < 0 || b >= h->dims.B_max || k < 0 || k >= h->dims.N || which < 0 || which > 3)
         return fail(h, NMPC_E_ARG, "index out of range");
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     HIP_TRY(h, hipDeviceSynchronize());
     if (h->dims.model_id == NMPC_MODEL_DOUBLE_INTEGRATOR) return read_tile<nmpc::DoubleIntegrator>(h, b, k, which, out_host);
     if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) return fail(h, NMPC_E_ARG, "use nmpc_debug_read_workspace for the whole-body model");
@@ -535,7 +542,8 @@ int nmpc_debug_read_workspace(void* handle, int b, size_t offset, size_t count, 
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !out_host) return fail(h, NMPC_E_ARG, "null argument");
     if (b < 0 || b >= h->dims.B_max || offset + count > h->ws_stride) return fail(h, NMPC_E_ARG, "index out of range");
-    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(out_host, h->ws + (size_t)b * h->ws_stride + offset, count * sizeof(float), hipMemcpyDeviceToHost));
     return NMPC_OK;

@@ -7,6 +7,8 @@
 // the state table is 1.76 GB: it stays in HBM next to the rollouts that fill it.
 #include <hip/hip_runtime.h>
 
+#include "nmpc_device_guard.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -175,7 +177,10 @@ int launched() {
 // than that runs a second, mostly idle round), at most STAT_BLOCKS_MAX (the scratch size).
 template <int COLS, int PASS>
 int resident_blocks() {
-    static int cached = 0;
+    static int cache[16] = {0};                 // per device: the occupancy query is the device's, not the process's
+    int dev_now = 0;
+    if (hipGetDevice(&dev_now) != hipSuccess || dev_now < 0 || dev_now >= 16) return STAT_BLOCKS_MAX;
+    int& cached = cache[dev_now];
     if (cached == 0) {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -210,6 +215,7 @@ int nmpc_ring_append(const float* src, int row_len, long long n, float* ring, lo
     if (!src || !ring) return dfail(NMPC_E_ARG, "null argument");
     if (row_len < 1 || n < 0 || limit < 1 || first_slot < 0 || first_slot >= limit)
         return dfail(NMPC_E_ARG, "need row_len >= 1, n >= 0, limit >= 1, 0 <= first_slot < limit");
+    nmpc::DeviceGuard guard(nmpc::device_of(ring));
     const long long skip = n > limit ? n - limit : 0;
     const size_t elems = (size_t)(n - skip) * row_len;
     if ((elems + 255) / 256 > 0x7fffffffULL) return dfail(NMPC_E_ARG, "append too large for one launch");
@@ -224,6 +230,7 @@ int nmpc_column_stats(const float* data, long long rows, int cols, double* mean,
                       void* stream) {
     if (!data || !mean || !std_out || !scratch) return dfail(NMPC_E_ARG, "null argument");
     if (rows < 1 || cols < 1 || cols > 64) return dfail(NMPC_E_ARG, "need rows >= 1, 1 <= cols <= 64");
+    nmpc::DeviceGuard guard(nmpc::device_of(data));
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (cols) {   // the reference's row widths: state 44, action 12, contact goal 8, velocity goal 3
         case 44: column_stats<44>(st, data, rows, cols, mean, std_out, scratch); break;
@@ -246,6 +253,7 @@ int nmpc_assemble_batch(const float* states, int n_state, const double* s_mean, 
         return dfail(NMPC_E_ARG, "goals / actions / y missing for a non-zero width");
     if ((s_mean == nullptr) != (s_std == nullptr) || (g_mean == nullptr) != (g_std == nullptr))
         return dfail(NMPC_E_ARG, "mean and std come in pairs");
+    nmpc::DeviceGuard guard(nmpc::device_of(states));
     const size_t elems = (size_t)n_idx * (n_state + n_goal + n_action);
     hipLaunchKernelGGL(assemble_batch_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), states, n_state, s_mean, s_std, s_first, goals, n_goal, g_mean, g_std,

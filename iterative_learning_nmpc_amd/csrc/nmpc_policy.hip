@@ -8,6 +8,8 @@
 // Adam are small HBM-bound kernels around it.
 #include <hip/hip_runtime.h>
 
+#include "nmpc_device_guard.hpp"
+
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -609,7 +611,8 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)},
         {&p->part_b, (size_t)L * RCHUNK * H}, {&p->loss_part, (Bm * dims->n_out + 255) / 256 + 1},
         {&p->sign_count, (size_t)dims->n_out}};
-    hipError_t e = hipSetDevice(device_id);
+    nmpc::DeviceGuard guard(device_id);
+    hipError_t e = guard.err;
     for (auto& b : bufs) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b.ptr), b.n * sizeof(float));
         if (e == hipSuccess) e = hipMemset(*b.ptr, 0, b.n * sizeof(float));
@@ -627,7 +630,7 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
 void nmpc_policy_destroy(void* handle) {
     Policy* p = static_cast<Policy*>(handle);
     if (!p) return;
-    (void)hipSetDevice(p->device);
+    nmpc::DeviceGuard guard(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
                     p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part, p->sign_count};
     for (float* q : all) if (q) (void)hipFree(q);
@@ -650,7 +653,8 @@ int nmpc_policy_set_params(void* handle, const float* theta, const float* runnin
     if (!p || !theta) return pfail(p, NMPC_E_ARG, "null argument");
     if (p->d.batch_norm && (!running_mean || !running_var)) return pfail(p, NMPC_E_ARG, "running statistics missing");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    PTRY(p, hipSetDevice(p->device));
+    nmpc::DeviceGuard guard(p->device);
+    PTRY(p, guard.err);
     PTRY(p, hipMemcpyAsync(p->theta, theta, p->n_theta * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (p->d.batch_norm) {
         const size_t n = (size_t)p->d.n_hidden * p->d.hidden * sizeof(float);
@@ -667,7 +671,8 @@ int nmpc_policy_get_params(void* handle, float* theta, float* running_mean, floa
     Policy* p = static_cast<Policy*>(handle);
     if (!p || !theta) return pfail(p, NMPC_E_ARG, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    PTRY(p, hipSetDevice(p->device));
+    nmpc::DeviceGuard guard(p->device);
+    PTRY(p, guard.err);
     PTRY(p, hipMemcpyAsync(theta, p->theta, p->n_theta * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (p->d.batch_norm && running_mean && running_var) {
         const size_t n = (size_t)p->d.n_hidden * p->d.hidden * sizeof(float);
@@ -684,7 +689,8 @@ int nmpc_policy_forward(void* handle, int B, const float* X, float* Y, void* str
     if (!X || !Y) return pfail(p, NMPC_E_ARG, "null argument");
     if (B < 0 || B > p->d.batch_max) return pfail(p, NMPC_E_ARG, "B exceeds batch_max");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    PTRY(p, hipSetDevice(p->device));
+    nmpc::DeviceGuard guard(p->device);
+    PTRY(p, guard.err);
     forward(p, B, X, Y, false, st);
     PTRY(p, hipGetLastError());
     return NMPC_OK;
@@ -699,7 +705,8 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
     if (p->d.batch_norm && B < 2) return pfail(p, NMPC_E_ARG, "BatchNorm in train mode needs B >= 2");
     if (!(lr > 0.0f)) return pfail(p, NMPC_E_ARG, "learning rate must be positive");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    PTRY(p, hipSetDevice(p->device));
+    nmpc::DeviceGuard guard(p->device);
+    PTRY(p, guard.err);
     const int L = p->d.n_hidden, H = p->d.hidden, no = p->d.n_out;
     const bool bn = p->d.batch_norm != 0;
     if (p->grad_dirty) {                                    // normally both are left zero by adam_kernel
@@ -763,6 +770,7 @@ int nmpc_weighted_sample(const float* weights, long long n, int num_samples, uns
     const long long nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     double* cdf = scratch;
     double* tot = scratch + n;                        // nb + 1 doubles
+    nmpc::DeviceGuard guard(nmpc::device_of(weights));
     hipLaunchKernelGGL(scan_block_totals_kernel, dim3((unsigned)nb), dim3(256), 0, st, weights, n, tot);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(64), 0, st, tot, nb);
     hipLaunchKernelGGL(scan_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, weights, n, tot, cdf);
@@ -778,6 +786,7 @@ int nmpc_gather_rows(const float* src, long long n_rows, int row_len, const int*
     if (!src || !idx || !dst) return pfail(nullptr, NMPC_E_ARG, "null argument");
     if (row_len < 1 || n_idx < 0 || n_rows < 1) return pfail(nullptr, NMPC_E_ARG, "need n_rows, row_len >= 1, n_idx >= 0");
     const size_t n = (size_t)n_idx * row_len;
+    nmpc::DeviceGuard guard(nmpc::device_of(src));
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        src, n_rows, row_len, idx, n_idx, dst);
     hipError_t e = hipGetLastError();

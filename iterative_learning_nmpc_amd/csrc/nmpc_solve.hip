@@ -1065,7 +1065,10 @@ __global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveAr
             else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }
         }
     }
-    if (status != NMPC_STATUS_NAN) {   // a NaN step leaves the iterate of the previous iteration
+    // a NaN step leaves the iterate of the previous iteration -- which, in a call that folded a warm-start shift into its
+    // first iteration, is the SHIFTED previous solution: it is written back so that the caller's node bookkeeping
+    // (last_node already advanced) and the trajectory stay aligned
+    if (status != NMPC_STATUS_NAN || a.shift > 0) {
         batched<10>((N + 1) * NX, lane, [&](int e) { const int k = e / NX; return AT(Xs, k, e - k * NX); },
                     [&](int e, float v) { Xg[e] = v; });
         batched<10>(N * NU, lane, [&](int e) { const int k = e / NU; return AT(Us, k, e - k * NU); },

@@ -10,6 +10,8 @@
 // are conflict-free LDS reads.  ~5 kFLOP per robot: the layer is latency-, not throughput-relevant.
 #include <hip/hip_runtime.h>
 
+#include "nmpc_device_guard.hpp"
+
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -244,7 +246,8 @@ int nmpc_torque_create(const nmpc_tree_model* mdl, int device_id, void** handle)
     std::memcpy(m.gravity, mdl->gravity, 12);
     Torque* t = new Torque();
     t->host = m; t->device = device_id;
-    hipError_t e = hipSetDevice(device_id);
+    nmpc::DeviceGuard guard(device_id);
+    hipError_t e = guard.err;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->dev), sizeof(Model));
     if (e == hipSuccess) e = hipMemcpy(t->dev, &m, sizeof(Model), hipMemcpyHostToDevice);
     if (e == hipSuccess)                                   // more than the default 64 KB of LDS per block
@@ -263,6 +266,7 @@ int nmpc_torque_create(const nmpc_tree_model* mdl, int device_id, void** handle)
 void nmpc_torque_destroy(void* handle) {
     Torque* t = static_cast<Torque*>(handle);
     if (!t) return;
+    nmpc::DeviceGuard guard(t->device);
     if (t->dev) (void)hipFree(t->dev);
     delete t;
 }
@@ -277,6 +281,7 @@ int nmpc_id_torques_batch(void* handle, int B, const float* q, const float* v, c
     Torque* t = static_cast<Torque*>(handle);
     if (!t) return tfail(nullptr, NMPC_E_ARG, "null handle");
     if (B == 0) return NMPC_OK;
+    nmpc::DeviceGuard guard(t->device);
     if (B < 0 || !q || !v || !a || !tau) return tfail(t, NMPC_E_ARG, "need B >= 0 and q, v, a, tau");
     const size_t lds = (size_t)t->host.n * SLOTS * TPB * sizeof(float);
     hipLaunchKernelGGL(id_torques_kernel, dim3((unsigned)((B + TPB - 1) / TPB)), dim3(TPB), lds, static_cast<hipStream_t>(stream),
@@ -290,6 +295,7 @@ int nmpc_pd_torques_batch(void* handle, int B, const float* tau_ff, const float*
     Torque* t = static_cast<Torque*>(handle);
     if (!t) return tfail(nullptr, NMPC_E_ARG, "null handle");
     if (B == 0) return NMPC_OK;
+    nmpc::DeviceGuard guard(t->device);
     if (B < 0 || !q || !v || !q_plan || !v_plan || !tau) return tfail(t, NMPC_E_ARG, "need B >= 0 and q, v, q_plan, v_plan, tau");
     const size_t n = (size_t)B * t->host.nu;
     hipLaunchKernelGGL(pd_torques_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), B,
@@ -303,6 +309,7 @@ int nmpc_pd_target_action_batch(void* handle, int B, const float* tau, const int
     Torque* t = static_cast<Torque*>(handle);
     if (!t) return tfail(nullptr, NMPC_E_ARG, "null handle");
     if (B == 0) return NMPC_OK;
+    nmpc::DeviceGuard guard(t->device);
     if (B < 0 || !tau || !q || !v || !action) return tfail(t, NMPC_E_ARG, "need B >= 0 and tau, q, v, action");
     if (!(kp != 0.0f)) return tfail(t, NMPC_E_ARG, "kp must not be zero");
     const size_t n = (size_t)B * t->host.nu;

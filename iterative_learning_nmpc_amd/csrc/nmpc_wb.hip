@@ -51,6 +51,7 @@ struct WbArgs {
     float reg, reg_e;
     int N, B;
     int max_sqp, n_ipm, yref_per_stage, it, shift;
+    int precision;      // 0: fp32; 1: bf16 residual Jacobian, J'WJ on the bf16 matrix pipe; 2: split bf16 (hi + lo)
     float nlp_tol, mu0, sigma, s_min, gamma, tau_min;
     const float* x0;
     const float* yref;
@@ -377,7 +378,11 @@ struct WbLds {
 template <int J>
 __device__ __forceinline__ void bcast_group(const float (&v)[8], float (&o)[8]) {
     int r0, r1, r2, r3, r4, r5, r6, r7;
-    asm volatile("v_readlane_b32 %0, %8, %16\n\tv_readlane_b32 %1, %9, %16\n\tv_readlane_b32 %2, %10, %16\n\t"
+    // The leading s_nop is the wait state gfx950 needs between a VALU write of a VGPR and a v_readlane of it: the
+    // hazard recognizer does not look into inline assembly, and the scheduler is free to sink the last FMA of the
+    // previous group to just in front of this one (found as a run-to-run varying 5e-5 error after an unrelated edit
+    // had changed the schedule).
+    asm volatile("s_nop 0\n\tv_readlane_b32 %0, %8, %16\n\tv_readlane_b32 %1, %9, %16\n\tv_readlane_b32 %2, %10, %16\n\t"
                  "v_readlane_b32 %3, %11, %16\n\tv_readlane_b32 %4, %12, %16\n\tv_readlane_b32 %5, %13, %16\n\t"
                  "v_readlane_b32 %6, %14, %16\n\tv_readlane_b32 %7, %15, %16\n\ts_nop 1"
                  : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3), "=s"(r4), "=s"(r5), "=s"(r6), "=s"(r7)
@@ -493,25 +498,65 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         float grow[XT];
 #pragma unroll
         for (int j = 0; j < XT; ++j) { const int col = 16 * j + c; grow[j] = rec[R_GQ + (col < 36 ? col : 0)]; }
+        // mixed precision (BASELINE configs[4]): the scaled Jacobian rounded to bf16 -- or split into a bf16 head and a
+        // bf16 tail, J = hi + lo -- and contracted on the bf16 matrix pipe with fp32 accumulation
+        // (v_mfma_f32_16x16x16_bf16: one instruction per 16 residual rows where fp32 takes four steps); the accumulator
+        // layout of a tile is that instruction's operand layout (nmpc_tile.hpp).  Everything downstream stays fp32.
+        s16x4 Jh[JT][XT], Jl[JT][XT];
+        if (a.precision != 0) {
 #pragma unroll
-        for (int i = 0; i < XT; ++i)
+            for (int t = 0; t < JT; ++t)
 #pragma unroll
-            for (int j = 0; j < XT; ++j) {
-                f32x4 acc = zero4();
+                for (int j = 0; j < XT; ++j) {
+                    Jh[t][j] = to_bf16x4(J[t][j]);
+                    f32x4 back;
 #pragma unroll
-                for (int t = 0; t < JT; ++t) acc = xty(J[t][i], J[t][j], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
-                    float v = acc[r];
-                    if (i == j && r == (c & 3)) v += term ? qdiag_e[i] : qdiag[i];      // row == col <=> r == c - 4q
-                    if (col == HX && row < 36) v += gcol[i][r];
-                    if (row == HX && col < 36) v += grow[j];
-                    if (row == HX && col == HX) v = 0.0f;
-                    acc[r] = v;
+                    for (int r = 0; r < 4; ++r) back[r] = __uint_as_float(((unsigned)(unsigned short)Jh[t][j][r]) << 16);
+                    Jl[t][j] = to_bf16x4(J[t][j] - back);
                 }
-                store_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane, acc);
+        }
+        // diagonal, gradient column / row, and store -- called right behind the products of each precision branch, so
+        // that the MFMA results are consumed in the block that produced them
+        auto finish = [&](int i, int j, f32x4 acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * q4 + r, col = 16 * j + c;
+                float v = acc[r];
+                if (i == j && r == (c & 3)) v += term ? qdiag_e[i] : qdiag[i];      // row == col <=> r == c - 4q
+                if (col == HX && row < 36) v += gcol[i][r];
+                if (row == HX && col < 36) v += grow[j];
+                if (row == HX && col == HX) v = 0.0f;
+                acc[r] = v;
             }
+            store_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane, acc);
+        };
+        if (a.precision == 0) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int t = 0; t < JT; ++t) acc = xty(J[t][i], J[t][j], acc);
+                    finish(i, j, acc);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int t = 0; t < JT; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jh[t][j], acc, 0, 0, 0);
+                        if (a.precision == 2) {      // (hi + lo)'(hi + lo) without the lo'lo term (2^-16 of the product)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jl[t][j], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jl[t][i], Jh[t][j], acc, 0, 0, 0);
+                        }
+                    }
+                    finish(i, j, acc);
+                }
+        }
     }
     WB_STAMP(12);
     // cost, active rows, cold start of the interior point: s = max(-c, s_min), lam = mu0 / s

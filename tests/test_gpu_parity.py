@@ -483,7 +483,8 @@ def test_mixed_precision_barrier_product(dev, oracle64):
     eX, eU = rel(X, Xo), rel(U, Uo)
     print(f"mixed precision: rel-L2 X {eX:.2e} U {eU:.2e}")
     assert np.array_equal(st, sto)
-    assert 1e-4 < eX < 0.25 and eU < 0.25, (eX, eU)      # runs, converges to the neighbourhood, is NOT the fp32 path
+    # the documented deviation (8e-2 / 3e-2 on this workload), within a factor of two either way
+    assert 4e-2 < eX < 1.6e-1 and 1.5e-2 < eU < 6e-2, (eX, eU)
 
 
 @pytest.mark.gpu
