@@ -516,12 +516,11 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                rec = json.load(open(tp))
-                key = f"{'wb_' if wbm else ''}B{B}_ipm{a.ipm}_sqp{a.sqp}"
-                if rec.get("kernel_sources_sha") == kernel_sources_sha():
-                    traffic, traffic_source = rec.get(key), rec.get("source")
-                else:
-                    traffic_source = f"stale: {rec.get('source')} profiled other kernel sources; traffic withheld"
+                rec = json.load(open(tp)).get(f"{'wb_' if wbm else ''}B{B}_ipm{a.ipm}_sqp{a.sqp}_p{a.precision}")
+                if rec and rec.get("kernel_sources_sha") == kernel_sources_sha():
+                    traffic, traffic_source = rec["bytes"], f"{rec['source']} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of {rec['kernel']}, kernel sources {rec['kernel_sources_sha']})"
+                elif rec:
+                    traffic_source = f"stale: {rec.get('source')} was measured on kernel sources {rec.get('kernel_sources_sha')}, this build is {kernel_sources_sha()}; traffic withheld"
             except Exception:
                 traffic = None
         out = {
