@@ -111,7 +111,7 @@ def rollout_mode(a, world, rank, dev, dist):
     replans (first one a 15-iteration cold start), tracking errors [B, 50] against the nominal rollout,
     one all-gather of the errors per learning iteration, OOD weights on every rank."""
     from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC
-    from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors, learning_update
+    from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors, learning_update, ood_threshold
     from iterative_learning_nmpc_amd.solver import tracking_error
     B, T = a.rollouts, 2.0
     rng = np.random.default_rng(1000 * rank)
@@ -132,7 +132,7 @@ def rollout_mode(a, world, rank, dev, dist):
         S, _ = mpc.open_loop_device(x0, T, push)
         err = tracking_error(S, S[0].contiguous(), with_weights=False)
         err_all = all_gather_tracking_errors(err, world * B)
-        ood, weights = learning_update(err_all)
+        ood, weights = learning_update(err_all, threshold=ood_threshold(S.shape[2]))      # 19-slot rows: 2.59 (parallel.py)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()

@@ -61,6 +61,20 @@ def all_gather_tracking_errors(err_local: torch.Tensor, total: int) -> torch.Ten
     return torch.cat(parts)
 
 
+OOD_THRESHOLD_REFERENCE = 4.0     # on the reference's 44-slot state row (data_collection_force_perturbation.py:149)
+
+
+def ood_threshold(n_state: int) -> float:
+    """The out-of-distribution threshold for a recorded state row of `n_state` slots.
+
+    The reference's 4.0 is a Euclidean distance over the 43 non-phase slots of its row [phase, v(18), q[2:](17),
+    base_wrt_feet(8)] (DAgger/utils/RolloutMPC.py:221), i.e. a per-slot RMS deviation of 4.0 / sqrt(43) = 0.61.  The
+    centroidal rollouts record the 19-slot sub-vector that plant has ([phase, v(6), z, yaw, pitch, roll,
+    base_wrt_feet(8)], include/nmpc.h) [decl]; the threshold is mapped by keeping that per-slot RMS deviation:
+    4.0 sqrt((n_state - 1) / 43) -- 2.59 for 19 slots, 4.0 for 44."""
+    return OOD_THRESHOLD_REFERENCE * ((n_state - 1) / 43.0) ** 0.5
+
+
 def learning_update(err_all: torch.Tensor, threshold: float = 4.0, ood_weight: float = 5.0):
     """OOD mask and sampling weights from the gathered errors (identical on every rank)."""
     ood = err_all > threshold

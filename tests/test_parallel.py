@@ -60,3 +60,10 @@ def test_all_gather_of_tracking_errors_gloo(tmp_path, world, total, K):
 def test_single_process_is_identity():
     e = torch.rand(5, 3)
     assert all_gather_tracking_errors(e, 5) is e
+
+
+def test_ood_threshold_mapping():
+    """4.0 on the reference's 44-slot row; the same per-slot RMS deviation on the centroidal 19-slot sub-vector"""
+    from iterative_learning_nmpc_amd.parallel import ood_threshold
+    assert ood_threshold(44) == 4.0
+    assert abs(ood_threshold(19) - 4.0 * (18 / 43) ** 0.5) < 1e-15 and abs(ood_threshold(19) - 2.588) < 1e-3
