@@ -21,7 +21,7 @@
 // the per-stage record, the elimination columns and the transposition buffer live in the LDS (31 KB at N = 30).
 #include <hip/hip_runtime.h>
 
-#include "../../include/nmpc.h"
+#include "/root/repo/include/nmpc.h"
 #include "nmpc_wb_model.hpp"
 
 namespace nmpc {
@@ -390,34 +390,56 @@ __device__ __forceinline__ void bcast_group(const float (&v)[8], float (&o)[8]) 
     o[0] = __int_as_float(r0); o[1] = __int_as_float(r1); o[2] = __int_as_float(r2); o[3] = __int_as_float(r3);
     o[4] = __int_as_float(r4); o[5] = __int_as_float(r5); o[6] = __int_as_float(r6); o[7] = __int_as_float(r7);
 }
-// rows J+1 .. NU-1 of the elimination step of pivot J, eight rows per group (the last group padded with row NU-1)
-template <int J, int FIRST>
+// Coupling mask of the inputs at a stage: the accelerations always couple (bits 0..17); the three force components of a
+// foot couple only while the foot stands -- a swing foot has a zero column in B~, no active pyramid row and a diagonal
+// cost, so its row and column of Huu are exactly diagonal: its multipliers are exact zeros and nothing below it changes.
+// The elimination is instantiated for the contact patterns of a trot (the two diagonal pairs, four-foot stance, flight)
+// with those rows and pivots left out at compile time (160 of the 435 multipliers of a two-foot stage), and for the full
+// mask, which is valid for every pattern.
+__host__ __device__ constexpr unsigned coupling_mask(unsigned stance) {
+    unsigned m = 0x3FFFFu;
+    for (int f = 0; f < 4; ++f) m |= ((stance >> f) & 1u) ? (0x7u << (WF + 3 * f)) : 0u;
+    return m;
+}
+// idx-th coupled row above `after`, or -1
+__host__ __device__ constexpr int coupled_row(unsigned mask, int after, int idx) {
+    for (int i = after + 1; i < NU; ++i)
+        if ((mask >> i) & 1u) { if (idx == 0) return i; --idx; }
+    return -1;
+}
+__host__ __device__ constexpr int coupled_rows_above(unsigned mask, int after) {
+    int n = 0;
+    for (int i = after + 1; i < NU; ++i) n += (mask >> i) & 1u;
+    return n;
+}
+// the coupled rows below pivot J, eight per group (the last group padded with its own last row)
+template <int J, unsigned MASK>
 __device__ __forceinline__ void ldl_update(float (&X)[NU], float wx) {
-    constexpr int first = FIRST, n = NU - first;
+    constexpr int n = coupled_rows_above(MASK, J);
 #pragma unroll
     for (int g = 0; g < (n + 7) / 8; ++g) {
         float v[8], l[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = X[(first + 8 * g + u < NU) ? first + 8 * g + u : NU - 1];
+        for (int u = 0; u < 8; ++u) {
+            constexpr int dummy = 0; (void)dummy;
+            const int idx = 8 * g + u < n ? 8 * g + u : n - 1;
+            v[u] = X[coupled_row(MASK, J, idx)];
+        }
         bcast_group<J>(v, l);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (first + 8 * g + u < NU) X[first + 8 * g + u] = fmaf(-l[u], wx, X[first + 8 * g + u]);
+            if (8 * g + u < n) X[coupled_row(MASK, J, 8 * g + u)] = fmaf(-l[u], wx, X[coupled_row(MASK, J, 8 * g + u)]);
     }
 }
-// Pivot J with 1/sqrt(d_J) in hand.  Row J+1 is updated first and the next pivot's broadcast + v_rsq are issued right
-// behind it, so that their latency runs under the updates of the rows J+2.. instead of in front of the next pivot.
-template <int J>
-__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok, float rs) {
-    X[J] *= rs;
-    if constexpr (J + 1 < NU) {
-        const float wx = X[J] * rs;
-        X[J + 1] = fmaf(-bcast(X[J + 1], J), wx, X[J + 1]);
-        const float d1 = bcast(X[J + 1], J + 1);
-        ok = ok && (d1 > 0.0f);
-        const float rs1 = __builtin_amdgcn_rsqf(d1);
-        if constexpr (J + 2 < NU) ldl_update<J, J + 2>(X, wx);
-        ldl_pivots<J + 1>(X, ok, rs1);
+template <int J, unsigned MASK>
+__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
+    if constexpr (J < NU) {
+        const float d = bcast(X[J], J);
+        ok = ok && (d > 0.0f);
+        const float rs = __builtin_amdgcn_rsqf(d);
+        X[J] *= rs;
+        if constexpr (((MASK >> J) & 1u) && coupled_rows_above(MASK, J) > 0) ldl_update<J, MASK>(X, X[J] * rs);
+        ldl_pivots<J + 1, MASK>(X, ok);
     }
 }
 
@@ -705,6 +727,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 for (int j = 0; j <= i; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
             const float* rk = recb;
             const float* ik = ipm + k * IPMW;
+            // contact pattern of the stage from the record's dt c_f (wave-uniform; read now: the record is replaced mid-stage)
+            const unsigned pat = __builtin_amdgcn_readfirstlane((rk[R_CDT] > 0.0f ? 1u : 0u) | (rk[R_CDT + 1] > 0.0f ? 2u : 0u) |
+                                                                (rk[R_CDT + 2] > 0.0f ? 4u : 0u) | (rk[R_CDT + 3] > 0.0f ? 8u : 0u));
             WB_STAMP(0);
             // ---- synthesise N~ = A~ - I and B~ tiles from the record (one LDS read per element)
             f32x4 Nt[XT][XT], Bt[XT][UT];
@@ -831,9 +856,13 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     }
                 }
             }
-            const float d0 = bcast(Xc[0], 0);
-            bool ok = d0 > 0.0f;
-            ldl_pivots<0>(Xc, ok, __builtin_amdgcn_rsqf(d0));
+            bool ok = true;
+            {
+                if (pat == 0x9u) ldl_pivots<0, coupling_mask(0x9u)>(Xc, ok);
+                else if (pat == 0x6u) ldl_pivots<0, coupling_mask(0x6u)>(Xc, ok);
+                else if (pat == 0x0u) ldl_pivots<0, coupling_mask(0x0u)>(Xc, ok);
+                else ldl_pivots<0, coupling_mask(0xFu)>(Xc, ok);
+            }
             qp_ok = qp_ok && ok;
             WB_STAMP(5);
             // transposed tiles: Ht[i][j] = (lower tile (i,j))', i >= j
@@ -964,7 +993,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         wave_sync();
         // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16).  The row of the next stage is
         // requested before this stage's is used (a stage is far shorter than a trip to the L2 / HBM: unprefetched, the
-        // forward sweep cost 6.9 k cycles per stage against 27 k for the backward stage).
+        // forward sweep cost 6.9 k cycles per stage against 27 k for the backward stage).  Measured and dropped (same box,
+        // tools/ab_wb.sh): three rows in flight with the record requested ahead of them, -5 % on the whole solve.
         const int urow = lane < NU ? lane : 0;
         const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
         auto load_krow = [&](int k, float (&row)[HX + 1]) {

@@ -86,6 +86,30 @@ def test_wholebody_active_friction_pyramid(dev, oracle64):
     assert (np.abs(U[:, :, 18:].reshape(B, 30, 4, 3)[~stance]) < 1e-3).all()     # swing feet carry no force
 
 
+def test_wholebody_any_contact_pattern(dev, oracle64):
+    """The elimination has static variants for the patterns of a trot (diagonal pairs, four-foot stance, flight) and the
+    full-mask code for everything else: random per-problem, per-stage patterns (pace, bound, three-legged ...) exercise
+    every path, including the hand-over between variants from stage to stage."""
+    B = 48
+    w = wl.wholebody_trot(B=B, N=30, seed=13)
+    rng = np.random.default_rng(5)
+    c = (rng.random((B, 31, 4)) < 0.6).astype(np.float64)
+    c[: B // 3] = w.params[: B // 3, :, :4]                                  # a third keeps its trot schedule
+    w.params = w.params.copy()
+    w.params[:, :, :4] = c
+    w.params[:, :, 4:8] = 1.0 - c
+    n_st = np.maximum(c[:, :30].sum(-1, keepdims=True), 1.0)
+    w.U = w.U.copy(); w.yref = w.yref.copy()
+    w.U[:, :, 18:] = 0.0
+    w.U[:, :, 20::3] = c[:, :30] * (-w.mp[5] * w.mp[1]) / n_st
+    w.yref[:, :, 52:64] = w.U[:, :, 18:]
+    s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2)
+    X, U, st, _ = _gpu_solve(s, w)
+    Xo, Uo, sto, _ = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2)
+    assert np.array_equal(st, sto)
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))
+
+
 @pytest.mark.parametrize("B,N", [(1, 30), (3, 25), (65, 30), (5, 7), (2, 64)])
 def test_wholebody_odd_batches_and_horizons(dev, oracle64, B, N):
     """ragged batches; the reference's own horizon (25 nodes, mpc_opt.py:11-13); the 64-lane limit of lane = stage"""
