@@ -715,6 +715,14 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
         }
         wave_sync();
+        // Q~ tiles (lower ones) are requested one and a half stages ahead of their use: for stage k-1 in the middle of
+        // stage k.  (A timing build that reads one cache-resident image instead of each stage's own ran 10 % faster:
+        // requested at the top of their own stage, the 6 KB did not arrive by the time H needs them.)
+        f32x4 Qn[XT][XT];
+#pragma unroll
+        for (int i = 0; i < XT; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)(N - 1) * QT_FLOATS + (i * XT + j) * IMG, lane);
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
             // prefetch: next record, this stage's Q~ tiles were requested ... (Q of stage k is loaded here; the
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) Q[i][j] = load_tile(Qimg + (size_t)k * QT_FLOATS + (i * XT + j) * IMG, lane);
+                for (int j = 0; j <= i; ++j) Q[i][j] = Qn[i][j];
             const float* rk = recb;
             const float* ik = ipm + k * IPMW;
             // contact pattern of the stage from the record's dt c_f (wave-uniform; read now: the record is replaced mid-stage)
@@ -864,6 +872,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 else ldl_pivots<0, coupling_mask(0xFu)>(Xc, ok);
             }
             qp_ok = qp_ok && ok;
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)kn * QT_FLOATS + (i * XT + j) * IMG, lane);
             WB_STAMP(5);
             // transposed tiles: Ht[i][j] = (lower tile (i,j))', i >= j
             f32x4 Ht[XT][XT];
@@ -969,7 +981,12 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
                 for (int i = 0; i < UT; ++i)
 #pragma unroll
-                    for (int j = 0; j < XT; ++j) store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
+                    for (int j = 0; j < XT; ++j) {
+#ifdef WB_T_NOKSTORE     // timing build (tools/ab_wb.sh): no gain stores -- results are wrong, the time tells what the stores cost
+                        if (a.B < 0)
+#endif
+                        store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
+                    }
             }
             WB_STAMP(15);
         }
@@ -994,7 +1011,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16).  The row of the next stage is
         // requested before this stage's is used (a stage is far shorter than a trip to the L2 / HBM: unprefetched, the
         // forward sweep cost 6.9 k cycles per stage against 27 k for the backward stage).  Measured and dropped (same box,
-        // tools/ab_wb.sh): three rows in flight with the record requested ahead of them, -5 % on the whole solve.
+        // tools/ab_wb.sh): three rows in flight (two stages ahead), in either load order, -5 ... -7 % on the whole solve.
         const int urow = lane < NU ? lane : 0;
         const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
         auto load_krow = [&](int k, float (&row)[HX + 1]) {
