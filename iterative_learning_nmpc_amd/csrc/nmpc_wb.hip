@@ -109,7 +109,10 @@ __device__ __forceinline__ int yref_of_state(int s) {
 
 // ------------------------------------------------------------------------------------------------------------
 // Linearisation: thread t <-> (problem b, node k), k = N is the terminal node.
-__global__ __launch_bounds__(64) void nmpc_wb_linearize_kernel(const WbArgs a) {
+#ifndef WB_LIN_WAVES
+#define WB_LIN_WAVES 1
+#endif
+__global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(const WbArgs a) {
     const int N = a.N;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)a.B * (N + 1)) return;

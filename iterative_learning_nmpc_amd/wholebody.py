@@ -40,6 +40,30 @@ def feet_position_w(q: np.ndarray, geom=GEOMETRY) -> np.ndarray:
     return q[:3] + feet_in_base(q[6:], geom) @ R.T
 
 
+def _rotations(ypr: np.ndarray) -> np.ndarray:
+    """[..., 3] (yaw, pitch, roll) -> [..., 3, 3] R = Rz Ry Rx, vectorised `rpy_to_matrix`"""
+    y, p, r = ypr[..., 0], ypr[..., 1], ypr[..., 2]
+    cy, sy, cp, sp, cr, sr = np.cos(y), np.sin(y), np.cos(p), np.sin(p), np.cos(r), np.sin(r)
+    return np.stack([np.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], -1),
+                     np.stack([sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], -1),
+                     np.stack([-sp, cp * sr, cp * cr], -1)], -2)
+
+
+def feet_position_w_batch(q: np.ndarray, geom=GEOMETRY) -> np.ndarray:
+    """[B, 18] -> [B, 4, 3]"""
+    q = np.asarray(q, float)
+    return q[:, None, :3] + np.einsum("bij,bfj->bfi", _rotations(q[:, 3:6]), feet_in_base(q[:, 6:], geom))
+
+
+def centroidal_momentum_batch(q: np.ndarray, v: np.ndarray, mass: float, inertia) -> np.ndarray:
+    """[B, 18] x 2 -> [B, 6]"""
+    q, v = np.asarray(q, float), np.asarray(v, float)
+    sy, cy, sx, cx = np.sin(q[:, 4]), np.cos(q[:, 4]), np.sin(q[:, 5]), np.cos(q[:, 5])
+    yd, pd, rd = v[:, 3], v[:, 4], v[:, 5]
+    w_body = np.stack([-sy * yd + rd, cy * sx * yd + cx * pd, cx * cy * yd - sx * pd], -1)      # E(theta) thetadot
+    return np.concatenate([mass * v[:, :3], np.einsum("bij,bj->bi", _rotations(q[:, 3:6]), np.asarray(inertia, float) * w_body)], -1)
+
+
 def centroidal_momentum(q: np.ndarray, v: np.ndarray, mass: float, inertia) -> np.ndarray:
     """`pin_data.hg` of the declared model: [m rdot, R I_b E(theta) thetadot] (v[3:6] are Euler rates)."""
     q, v = np.asarray(q, float), np.asarray(v, float)

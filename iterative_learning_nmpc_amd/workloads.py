@@ -187,22 +187,25 @@ def wholebody_trot(B: int = 8192, N: int = 30, seed: int = 0, sigma_joint: float
     contacts = planner.get_contacts_batch(i_node, N + 1).astype(np.float64)      # [B,4,N+1]
 
     inertia = mp[2:5]
-    x0 = np.zeros((B, d["nx"]))
+    from .mpc import base_ref_vel_tracking_batch                 # the vectorised restatement of mpc.py:210-272
+    x0 = np.concatenate([q0, v0, wb.centroidal_momentum_batch(q0, v0, mp[1], inertia)], axis=1)
     params = np.zeros((B, N + 1, d["np"]))
+    params[:, :, 0:4] = np.moveaxis(contacts, 1, 2)
+    params[:, :, 4:8] = 1.0 - params[:, :, 0:4]                                   # peak = 1 - contact (contact_planner.py:136-149)
+    feet_w = wb.feet_position_w_batch(q0)
+    # anchor_plane_points for the batch: a foot in contact at node 0 keeps its position up to its first swing node
+    first_swing = np.argmin(contacts, axis=2)                                      # [B, 4]; 0 if it never swings (nothing anchored)
+    anchored = (np.arange(N + 1)[None, None, :] < first_swing[:, :, None]) & (contacts[:, :, :1] > 0.5)     # [B, 4, N+1]
+    pp = np.where(anchored[..., None], feet_w[:, :, None, :], 0.0)                 # [B, 4, N+1, 3]
+    params[:, :, 8:] = np.moveaxis(pp, 1, 2).reshape(B, N + 1, 12)
+    ref_state = np.zeros((B, 12))
+    ref_state[:, :2] = q0[:, :2]
+    ref_state[:, 3] = q0[:, 3]
+    base, base_e = base_ref_vel_tracking_batch(q0, v_des, np.zeros((B, 3)), ref_state, T, gait.nom_height)
     yref = np.zeros((B, N, d["ny"]))
     yref_e = np.zeros((B, d["ny_e"]))
-    for b in range(B):
-        x0[b, :18], x0[b, 18:36] = q0[b], v0[b]
-        x0[b, 36:] = wb.centroidal_momentum(q0[b], v0[b], mp[1], inertia)
-        params[b, :, 0:4] = contacts[b].T
-        params[b, :, 4:8] = 1.0 - contacts[b].T                                  # peak = 1 - contact (contact_planner.py:136-149)
-        params[b, :, 8:] = anchor_plane_points(contacts[b], wb.feet_position_w(q0[b])).reshape(N + 1, 12)
-        ref_state = np.zeros(12)
-        ref_state[:2] = q0[b, :2]
-        ref_state[3] = q0[b, 3]
-        base, base_e = base_ref_vel_tracking(q0[b], v_des[b], np.zeros(3), ref_state, T, gait.nom_height)
-        yref[b, :, 0:12] = base
-        yref_e[b, 0:12] = base_e
+    yref[:, :, 0:12] = base[:, None, :]
+    yref_e[:, 0:12] = base_e
     yref[:, :, 12:24] = wb.Q_HOME                  # joint reference = nominal pose, zero rates (solver.py:175-177)
     yref[:, :, 48:52] = gait.step_height           # swing-height reference (solver.py:170)
     yref_e[:, 12:24] = wb.Q_HOME
