@@ -957,7 +957,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j < i; ++j) *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = P[i][j];
-            WB_STAMP(13);
             wave_sync();
 #pragma unroll
             for (int i = 0; i < XT; ++i)
@@ -966,7 +965,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     const float* ph = hbuf + (16 * j + 4 * q4) * LDH + 16 * i + c;
                     P[j][i] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
                 }
-            WB_STAMP(14);
             {
                 f32x4 Kt[UT][XT];
 #pragma unroll
@@ -991,7 +989,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                         store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
                     }
             }
-            WB_STAMP(15);
         }
         WB_STAMP(8);
         phase_sync();
@@ -1036,6 +1033,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 if (4 * j4 + 3 <= HX) a3 = fmaf(row[(4 * j4 + 3 <= HX) ? 4 * j4 + 3 : 0], dx[3], a3);
             }
             const float du = (a0 + a1) + (a2 + a3);
+            WB_STAMP(13);
             if (lane < NU) { duv[lane] = du; AT(oU, k, lane) = du; }
             wave_sync();
             const float* rk = recb;
@@ -1081,10 +1079,12 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 }
                 xn += (i >= 39) ? acc_a : (i >= 36) ? acc_l : 0.0f;
             }
+            WB_STAMP(14);
             wave_sync();
             if (lane < NX) { dxv[lane] = xn; AT(oX, k + 1, lane) = xn; }
             *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_next;
             wave_sync();
+            WB_STAMP(15);
         };
         {
             float rowA[HX + 1], rowB[HX + 1];

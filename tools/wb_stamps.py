@@ -22,4 +22,4 @@ tot = m[:13].sum()
 print(f"B={B}: {tot:.0f} cycles per wave and solve call; per backward stage {m[:8].sum() / 180:.0f}")
 for n, v in zip(names, m):
     print(f"  {n:22s} {v:12.0f}  {100 * v / tot:5.1f} %   per stage {v / 180:8.0f}")
-print(f"  inside 'P+/K + prefetch' (also counted there? no: separate slots): P+ MFMAs {m[13] / 180:.0f}, mirror {m[14] / 180:.0f}, K MFMAs + stores {m[15] / 180:.0f} per stage")
+print(f"  forward stage split (separate slots, not in the table's 'forward sweeps'): du = K dx {m[13] / 180:.0f}, dx+ {m[14] / 180:.0f}, hand-over {m[15] / 180:.0f} per stage")
