@@ -422,7 +422,7 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // Two kernels rather than one loop with everything: measured, the mere presence of the other
 // variants in the kernel costs the common ones 2.5 % (code layout, register allocation).
 // Registers: the resident variant runs one wave per SIMD and is compiled for that (second launch-bound
-// = waves per SIMD), so the ~45 values that do not fit into 256 VGPRs spill into AGPRs -- one
+// = waves per SIMD), so the values that do not fit into 256 VGPRs (35 in this build: profiles/r02_isa_resources.md) spill into AGPRs -- one
 // v_accvgpr move each -- instead of scratch memory, whose reloads sat in the interior-point update behind a
 // vmcnt(0) each (measured: -6 % per solve call).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs
 // keep their VGPR operands (with AGPRs available the compiler otherwise moves the accumulators there and
