@@ -277,3 +277,22 @@ def test_converged_oracle_solution_is_the_optimum_of_an_independent_nlp_solver(o
     G, h, act = o.constraints(1, w.mp, w.params[0, 0])
     assert ((G @ Us[0] - h)[act > 0] > -1e-6).any()                      # the pyramid is active in the optimum
     assert np.abs(U[0] - Us).max() < 1e-5 * np.abs(Us).max() and np.abs(X[0] - Xs).max() < 1e-5      # measured 1e-6 / 8e-7
+
+
+def test_converged_oracle_solution_equals_slsqp_optimum_at_full_horizon(oracle64, golden_dir):
+    """The same cross-check at the horizon of BASELINE configs[1] (N = 50): scipy's SLSQP needs ten minutes for the
+    1 212-variable NLP, so its optimum is a fixture (tests/golden/make_golden_slsqp_n50.py); the oracle, converged with the
+    barrier driven to zero, reaches that point: 3e-7 relative on the inputs, 2e-6 absolute on the states, pyramid active."""
+    o = oracle64
+    g = np.load(os.path.join(golden_dir, "slsqp_centroidal_n50.npz"))
+    w = wl.centroidal_trot(B=1, N=50, seed=int(g["seed"]))
+    w.mp = w.mp.copy(); w.mp[6] = float(g["mu"])
+    w.yref = w.yref.copy(); w.yref[:, :, 6] = float(g["vx_ref"])
+    X, U, st, _ = o.solve_batch(1, 50, w.mp, o.opt(max_sqp_iter=40, n_ipm=60, tau_min=1e-10, mu0=1.0, nlp_tol=1e-10,
+                                                   reg=w.meta["reg"], reg_e=w.meta["reg_e"], yref_per_stage=1),
+                                w.W, w.W_e, w.x0, w.yref, w.yref_e, w.params, w.X, w.U)
+    assert st[0] == 0
+    G, h, act = o.constraints(1, w.mp, w.params[0, 0])
+    assert ((G @ g["Us"][0] - h)[act > 0] > -1e-6).sum() >= 2                      # binding pyramid faces in the optimum
+    assert np.abs(U[0] - g["Us"]).max() < 2e-6 * np.abs(g["Us"]).max() and np.abs(X[0] - g["Xs"]).max() < 1e-5, \
+        (np.abs(U[0] - g["Us"]).max() / np.abs(g["Us"]).max(), np.abs(X[0] - g["Xs"]).max())
