@@ -427,8 +427,11 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // vmcnt(0) each (measured: -6 % per solve call).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs
 // keep their VGPR operands (with AGPRs available the compiler otherwise moves the accumulators there and
 // copies them back and forth: slower).  The lean variant needs two waves per SIMD and has no AGPRs left.
+#ifndef NMPC_RES_WAVES
+#define NMPC_RES_WAVES 1      // diagnostic builds (tools/occupancy_probe.py) compile the resident variant for two waves per SIMD
+#endif
 template <class M, bool LEAN, bool BF16B, bool ALLV>
-__global__ __launch_bounds__(64, LEAN ? 2 : 1) void nmpc_qp_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Cross-check of the oracle's whole-body model (model 2) by an independent NLP solver at a horizon of N nodes (default 10).
+
+    python tests/golden/make_golden_slsqp_wholebody.py [N]      # N = 10: 5.5 minutes, 499 iterations; writes slsqp_wholebody_n<N>.npz
+
+scipy's SLSQP on the NLP of one seeded whole-body problem (low friction: pyramid faces active; commanded forward speed),
+with analytic gradients: the cost gradient from the oracle's residual Jacobian, the constraint Jacobian from its A, B
+(both checked against finite differences in tests/test_oracle_wholebody.py).  72 N variables, 42 N equality constraints."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+from scipy.optimize import minimize
+from oracle.oracle import Oracle
+from iterative_learning_nmpc_amd import workloads as wl
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+o = Oracle("f64")
+full = wl.wholebody_trot(B=1, N=30, seed=4, sigma_joint=0.05)
+mp = full.mp.copy(); mp[6] = 0.1
+yref = full.yref[0, :N].copy(); yref[:, 6] = 1.0
+params, x0, W, We, yref_e = full.params[0, :N + 1], full.x0[0], full.W, full.W_e, full.yref_e[0]
+nx, nu = 42, 30
+unpack = lambda z: (np.vstack([x0, z[:N * nx].reshape(N, nx)]), z[N * nx:].reshape(N, nu))
+
+
+def cost_and_grad(z):
+    X, U = unpack(z)
+    c, gx, gu = 0.0, np.zeros((N + 1, nx)), np.zeros((N, nu))
+    for k in range(N):
+        r, J = o.wb_residuals(mp, X[k], U[k], params[k], yref[k])
+        c += 0.5 * (W * r * r).sum()
+        gx[k] = J.T @ (W * r)
+        gu[k, 6:18] = W[36:48] * r[36:48]
+        gu[k, 18:] = W[52:64] * r[52:64]
+    r, J = o.wb_residuals(mp, X[N], None, params[N], yref_e)
+    c += 0.5 * (We * r * r).sum()
+    gx[N] = J.T @ (We * r)
+    return c, np.concatenate([gx[1:].ravel(), gu.ravel()])
+
+
+def defects(z):
+    X, U = unpack(z)
+    return np.concatenate([o.dynamics(2, mp, X[k], U[k], params[k], jac=False) - X[k + 1] for k in range(N)])
+
+
+def defects_jac(z):
+    X, U = unpack(z)
+    J = np.zeros((N * nx, N * nx + N * nu))
+    for k in range(N):
+        _, A, Bm = o.dynamics(2, mp, X[k], U[k], params[k])
+        if k > 0:
+            J[k * nx:(k + 1) * nx, (k - 1) * nx:k * nx] = A
+        J[k * nx:(k + 1) * nx, k * nx:(k + 1) * nx] -= np.eye(nx)
+        J[k * nx:(k + 1) * nx, N * nx + k * nu:N * nx + (k + 1) * nu] = Bm
+    return J
+
+
+rows, rhs = [], []
+for k in range(N):
+    G, h, act = o.constraints(2, mp, params[k])
+    for j in np.nonzero(act)[0]:
+        r = np.zeros(N * nx + N * nu); r[N * nx + k * nu:N * nx + (k + 1) * nu] = -G[j]
+        rows.append(r); rhs.append(h[j])
+Gi, hi = np.array(rows), np.array(rhs)
+z0 = np.concatenate([full.X[0, 1:N + 1].ravel(), full.U[0, :N].ravel()]).astype(float)
+t = time.time()
+r = minimize(lambda z: cost_and_grad(z)[0], z0, jac=lambda z: cost_and_grad(z)[1], method="SLSQP",
+             constraints=[dict(type="eq", fun=defects, jac=defects_jac), dict(type="ineq", fun=lambda z: Gi @ z + hi, jac=lambda z: Gi)],
+             options=dict(maxiter=2000, ftol=1e-15))
+print("slsqp", r.success, r.message, r.nit, "time %.0f s" % (time.time() - t), "cost", r.fun)
+Xs, Us = unpack(r.x)
+X, U, st, _ = o.solve_batch(2, N, mp, o.opt(max_sqp_iter=60, n_ipm=60, tau_min=1e-10, mu0=1.0, nlp_tol=1e-10, reg=full.meta["reg"],
+                                             reg_e=full.meta["reg_e"], yref_per_stage=1), W, We, x0[None], yref[None], yref_e[None],
+                            params[None], full.X[:, :N + 1], full.U[:, :N])
+print("oracle status", st, "max diff U", np.abs(U[0] - Us).max(), "of", np.abs(Us).max(), "X", np.abs(X[0] - Xs).max())
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"slsqp_wholebody_n{N}.npz"), Xs=Xs, Us=Us, N=np.int64(N),
+                    seed=np.int64(4), mu=np.float64(0.1), vx_ref=np.float64(1.0), slsqp_iterations=np.int64(r.nit), slsqp_cost=np.float64(r.fun))

@@ -173,3 +173,28 @@ def test_anchor_plane_points_follow_the_reference_rule():
     assert (pp[:, 1] == [0, 0, 0.02]).all()          # not in contact at node 0
     assert (pp[:, 2] == [0, 0, 0.02]).all()          # in contact over the whole window: argmin = 0, nothing anchored
     assert (pp[:, 3] == [0, 0, 0.02]).all()
+
+
+def test_converged_wholebody_solution_equals_slsqp_optimum_over_ten_nodes(oracle64, golden_dir):
+    """The same cross-check over N = 10 nodes (a third of the horizon of BASELINE configs[2]) with ANALYTIC gradients: SLSQP
+    needs five minutes and 499 iterations for the 720-variable NLP, so its optimum is a fixture
+    (tests/golden/make_golden_slsqp_wholebody.py).  It stops at its line search's resolution, 3e-6 relative on the inputs and
+    8e-6 absolute on the states from the oracle's point; several pyramid faces bind there."""
+    import os
+    o = oracle64
+    g = np.load(os.path.join(golden_dir, "slsqp_wholebody_n10.npz"))
+    N = int(g["N"])
+    full = wl.wholebody_trot(B=1, N=30, seed=int(g["seed"]), sigma_joint=0.05)
+    mp = full.mp.copy(); mp[6] = float(g["mu"])
+    yref = full.yref[:, :N].copy(); yref[:, :, 6] = float(g["vx_ref"])
+    X, U, st, _ = o.solve_batch(2, N, mp, o.opt(max_sqp_iter=60, n_ipm=60, tau_min=1e-10, mu0=1.0, nlp_tol=1e-10,
+                                                reg=full.meta["reg"], reg_e=full.meta["reg_e"], yref_per_stage=1),
+                                full.W, full.W_e, full.x0, yref, full.yref_e, full.params[:, :N + 1], full.X[:, :N + 1], full.U[:, :N])
+    assert st[0] == 0
+    binding = 0
+    for k in range(N):
+        G, h, act = o.constraints(2, mp, full.params[0, k])
+        binding += int(((G @ g["Us"][k] - h)[act > 0] > -1e-6).sum())
+    assert binding >= 4, binding
+    assert np.abs(U[0] - g["Us"]).max() < 1e-5 * np.abs(g["Us"]).max() and np.abs(X[0] - g["Xs"]).max() < 3e-5, \
+        (np.abs(U[0] - g["Us"]).max() / np.abs(g["Us"]).max(), np.abs(X[0] - g["Xs"]).max())

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Diagnostic: what a second wave per SIMD is worth to nmpc_qp_kernel<Centroidal>.  Times solve calls of the library named by
+NMPC_HIP_LIB at horizons whose resident LDS image fits twice per SIMD (N <= 20: 18.5 KB) and at the benchmark horizon:
+
+    NMPC_HIP_LIB=$PWD/tools/_dbg/libnmpc_res2.so python tools/occupancy_probe.py      # built with -DNMPC_RES_WAVES=2
+"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from iterative_learning_nmpc_amd import workloads as wl
+from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+
+for N, B in ((20, 1024), (20, 8192), (50, 1024), (50, 8192)):
+    w = wl.centroidal_trot(B=B, N=N, seed=0)
+    s = BatchedNmpcSolver(w.model_id, w.N, B, "cuda:0")
+    s.set_model_params(w.mp)
+    s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+    s.set_max_qp_iter(6)
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+    X, U = t["X"].clone(), t["U"].clone()
+    for _ in range(5):
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], X, U)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(40):
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], X, U)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 40
+    print(f"{os.environ.get('NMPC_HIP_LIB', 'default')}: N={N} B={B}: {ms:.4f} ms per call, {B / ms * 1e3 / 1e6:.3f} M solves/s, "
+          f"{B * N / ms * 1e3 / 1e6:.1f} M stages/s", flush=True)

@@ -10,7 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "gpurun_out", "libnmpc_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 extra = [x for x in sys.argv[2:] if x.startswith("-D")]
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DNMPC_STAMPS", *extra,
+if os.environ.get("NMPC_STAMPS_LIB"):     # a stamped library built beforehand (hipcc cross-compiles off the GPU box)
+    out = os.environ["NMPC_STAMPS_LIB"]
+else:
+  subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DNMPC_STAMPS", *extra,
                 "-o", out, *[os.path.join(ROOT, "iterative_learning_nmpc_amd", "csrc", f)
                              for f in ("nmpc_api.hip", "nmpc_policy.hip", "nmpc_dataset.hip", "nmpc_torque.hip")]], check=True)
 os.environ["NMPC_HIP_LIB"] = out
