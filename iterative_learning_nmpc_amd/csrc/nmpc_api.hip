@@ -113,10 +113,11 @@ int launch_wb(Handle* h, nmpc::wb::WbArgs a, hipStream_t st) {
 
 // One SQP iteration = linearise (thread per stage) + QP/step (wave per problem).  Problems that
 // finish early (converged, NaN, QP failure) set their workspace flag and later launches skip them.
-// Two variants of the QP kernel (nmpc_solve.hip, Lds): LDS-resident stage arrays, one wave per SIMD, larger
-// batches in rounds -- the default at every batch size (measured: 2.18 M solves/s at B = 1024, 2.27 M at
-// 8192); the lean layout (stage arrays in the workspace, two waves per SIMD: 1.96 M at 8192) serves horizons
-// whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
+// Two variants of the QP kernel (nmpc_solve.hip, Lds).  Resident: stage arrays in the LDS (39.6 KB at N = 50: four waves per CU),
+// pinned to one wave per SIMD -- the choice while the batch fits that many waves (B <= 4 x CUs: 2.2 M solves/s at B = 1024).
+// Lean: stage arrays in the workspace, 17.7 KB, two waves per SIMD -- the choice for larger batches, where the second wave fills
+// the first one's dependency stalls (2.65 M at B = 8192 against 2.31 M resident), for horizons whose resident layout does not
+// fit the LDS, and NMPC_QP_VARIANT=lean.  Both run the same arithmetic in the same order (bit-identical results, tested).
 template <class M, bool LEAN, bool BF16B, bool ALLV>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {
     const nmpc::Lds<M, LEAN> L(a.N);
@@ -141,9 +142,16 @@ int launch_solve(Handle* h, nmpc::SolveArgs a, hipStream_t st) {
     if (a.N > 64 * nmpc::N_LANE_STAGES) return fail(h, NMPC_E_ARG, "horizon too long for the lane = stage phases");
     const long long nthreads = (long long)a.B * (a.N + 1);
     const unsigned lin_blocks = (unsigned)((nthreads + 63) / 64);
-    const size_t resident_bytes = (size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float);
-    const long long resident_waves = resident_bytes <= 160 * 1024 ? (long long)h->n_cu * (long long)((160 * 1024) / resident_bytes) : 0;
-    const bool lean = h->force_variant ? (h->force_variant > 1) : (resident_waves == 0);
+    // problems in flight: a CU holds as many waves as its 160 KB of LDS take, at most one (resident) or two (lean) per SIMD
+    auto in_flight = [&](size_t lds_bytes, long long per_simd) -> long long {
+        if (lds_bytes > 160 * 1024) return 0;
+        const long long by_lds = (long long)((160 * 1024) / lds_bytes);
+        return (long long)h->n_cu * (by_lds < 4 * per_simd ? by_lds : 4 * per_simd);
+    };
+    const long long resident_waves = in_flight((size_t)nmpc::Lds<M, false>(a.N).total * sizeof(float), 1);
+    const long long lean_waves = in_flight((size_t)nmpc::Lds<M, true>(a.N).total * sizeof(float), 2);
+    const bool lean = h->force_variant ? (h->force_variant > 1)
+                                       : (resident_waves == 0 || ((long long)a.B > resident_waves && lean_waves > resident_waves));
     // all static variants only where the model has more than its short list and the caller asked for them
     if constexpr (M::N_STATIC_MASKS > 4) {
         if (h->all_patterns) {

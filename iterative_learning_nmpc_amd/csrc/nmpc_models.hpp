@@ -54,6 +54,7 @@ struct DoubleIntegrator {
         return mp.umax > 0.f ? 0xFu : 0u;
     }
     __device__ static void gdot(const ModelParams&, const float (&v)[NU], float (&o)[NG]) {
+#pragma clang fp contract(off)   // same rounding in every caller: the QP kernel's variants are compared bit for bit
         o[0] = v[0]; o[1] = -v[0]; o[2] = v[1]; o[3] = -v[1];
     }
     // inputs that couple with others in Huu: all of them, always -> one static variant
@@ -315,13 +316,13 @@ struct Centroidal {
         return static_mask(i) == mask ? i : -1;
     }
     __device__ static void gdot(const ModelParams& mp, const float (&v)[NU], float (&o)[NG]) {
+#pragma clang fp contract(off)   // same rounding in every caller: the QP kernel's variants are compared bit for bit
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const float mz = mp.mu * v[3 * f + 2];
-            o[row_of(f, 0)] = v[3 * f] - mz;
-            o[row_of(f, 1)] = -v[3 * f] - mz;
-            o[row_of(f, 2)] = v[3 * f + 1] - mz;
-            o[row_of(f, 3)] = -v[3 * f + 1] - mz;
+            o[row_of(f, 0)] = __builtin_fmaf(-mp.mu, v[3 * f + 2], v[3 * f]);
+            o[row_of(f, 1)] = __builtin_fmaf(-mp.mu, v[3 * f + 2], -v[3 * f]);
+            o[row_of(f, 2)] = __builtin_fmaf(-mp.mu, v[3 * f + 2], v[3 * f + 1]);
+            o[row_of(f, 3)] = __builtin_fmaf(-mp.mu, v[3 * f + 2], -v[3 * f + 1]);
         }
     }
 };

@@ -166,24 +166,33 @@ struct RowStoreLane {
     }
 };
 
-// Arrays of the lane = stage phases (trajectories, steps, slacks, multipliers): FEATURE-major,
-// [feature][stage] with an odd stage stride NS, so consecutive lanes touch consecutive banks (LDS)
-// or consecutive addresses (workspace).  Offsets in floats from the start of the group.
+// Arrays of the lane = stage phases (trajectories, steps, slacks, multipliers).  Two layouts:
+//   LDS (resident variant): FEATURE-major, [feature][stage] with an odd stage stride NS, so consecutive lanes touch
+//       consecutive banks;
+//   workspace (lean variant): STAGE-major, [stage][16]: the lane that owns a stage moves its whole row with three or
+//       four 16 B accesses (a feature-major row costs one 4 B access per feature: 100 instead of 35 memory instructions
+//       per lane and interior-point iteration), and the forward sweep's row stores of a stage land in one cache line.
+// Offsets in floats from the start of the group; nX/nU/nG = extent of a state / input / constraint-row array for the
+// element-wise passes (padding of the stage-major rows is zero and stays zero).
 template <class M>
 struct StageArrays {
-    int NS;   // stage stride (odd, >= N+1)
+    int NS;   // feature-major: stage stride (odd, >= N+1)
+    int nX, nU, nG;
     int Xs, Us, dX, dU, dXp, dUp, sv, lv, total;
-    __host__ __device__ explicit StageArrays(int N) {
+    __host__ __device__ StageArrays(int N, bool stage_major) {
         NS = (N + 1) | 1;
+        nX = stage_major ? (N + 1) * TS : M::NX * NS;
+        nU = stage_major ? (N + 1) * TS : M::NU * NS;
+        nG = stage_major ? (N + 1) * TS : M::NG * NS;
         int o = 0;
-        Xs = o;  o += round4(M::NX * NS);
-        Us = o;  o += round4(M::NU * NS);
-        dX = o;  o += round4(M::NX * NS);
-        dU = o;  o += round4(M::NU * NS);
-        dXp = o; o += round4(M::NX * NS);
-        dUp = o; o += round4(M::NU * NS);
-        sv = o;  o += round4(M::NG * NS);
-        lv = o;  o += round4(M::NG * NS);
+        Xs = o;  o += round4(nX);
+        Us = o;  o += round4(nU);
+        dX = o;  o += round4(nX);
+        dU = o;  o += round4(nU);
+        dXp = o; o += round4(nX);
+        dUp = o; o += round4(nU);
+        sv = o;  o += round4(nG);
+        lv = o;  o += round4(nG);
         o += 4;                                   // sink for the idle lanes of the forward sweep
         total = o;
     }
@@ -209,7 +218,7 @@ struct WsLayout {
         umk = o; o += round4(N);
         cost = o; o += round4(N + 1);
         flag = o; o += 4;
-        lean = o; o += StageArrays<M>(N).total;     // lane = stage arrays of the lean-LDS kernel variant
+        lean = o; o += StageArrays<M>(N, true).total;     // lane = stage arrays of the lean-LDS kernel variant (stage-major)
         stride = (o + 63) & ~(size_t)63;
     }
 };
@@ -242,7 +251,7 @@ struct Lds {
     __host__ __device__ explicit Lds(int N) {
         const int NS = (N + 1) | 1;
         int o = 0;
-        arr = o; o += LEAN ? 0 : StageArrays<M>(N).total;
+        arr = o; o += LEAN ? 0 : StageArrays<M>(N, false).total;
         // sweep operands are STAGE-major, 16 floats per stage: the four tile registers of a lane
         // are one 16 B read (only the stage sweeps touch them after they are written)
         qv = o;  o += (N + 1) * TS;
@@ -427,11 +436,17 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // vmcnt(0) each (measured: -6 % per solve call).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs
 // keep their VGPR operands (with AGPRs available the compiler otherwise moves the accumulators there and
 // copies them back and forth: slower).  The lean variant needs two waves per SIMD and has no AGPRs left.
+// Floating-point contraction is OFF in the body of this kernel (the tile algebra in nmpc_sweep.hpp / nmpc_tile.hpp is MFMA and
+// explicit fma; this is about the lane = stage arithmetic) and every a*b + c that is meant as one operation is written as fmaf:
+// left to the compiler, which products get fused into the following add depends on the instantiation -- the resident and the
+// lean variant, compiled from the same expressions, came out 1e-5 apart after an unrelated change to their loads.
+#pragma clang fp contract(off)
 #ifndef NMPC_RES_WAVES
 #define NMPC_RES_WAVES 1      // diagnostic builds (tools/occupancy_probe.py) compile the resident variant for two waves per SIMD
 #endif
 template <class M, bool LEAN, bool BF16B, bool ALLV>
-__global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : NMPC_RES_WAVES, LEAN ? 2 : NMPC_RES_WAVES)))
+void nmpc_qp_kernel(const SolveArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
     int* flag = reinterpret_cast<int*>(ws + wl.flag);
     if (a.it > 0 && flag[0]) return;             // finished in an earlier iteration
     const Lds<M, LEAN> L(N);
-    const StageArrays<M> SA_(N);
+    const StageArrays<M> SA_(N, LEAN);
     const int NS = SA_.NS;
     // the stage arrays: LDS in the resident variant, workspace in the lean one (same code either way;
     // the variant is a template parameter so that every pointer has ONE address space)
@@ -466,7 +481,38 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
     unsigned* actm = reinterpret_cast<unsigned*>(smem + L.act);
     unsigned* umask = reinterpret_cast<unsigned*>(smem + L.umk);
     float* conv = smem + L.conv;
-#define AT(arr, k, i) (arr)[(i) * NS + (k)]
+#define AT(arr, k, i) (arr)[LEAN ? (k) * TS + (i) : (i) * NS + (k)]
+    // the row of stage k of a stage array (12 or 16 features): 16 B accesses in the stage-major layout
+    auto ld_row = [&](const float* arr_, int k, auto& out) {
+        constexpr int n = (int)(sizeof(out) / sizeof(float));
+        if constexpr (LEAN) {
+#pragma unroll
+            for (int g = 0; g < (n + 3) / 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(arr_ + k * TS + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < n) out[4 * g + r] = v[r];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < n; ++i) out[i] = AT(arr_, k, i);
+        }
+    };
+    auto st_row = [&](float* arr_, int k, const auto& in) {     // (the padding of a stage-major row is rewritten as zero)
+        constexpr int n = (int)(sizeof(in) / sizeof(float));
+        if constexpr (LEAN) {
+#pragma unroll
+            for (int g = 0; g < (n + 3) / 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (4 * g + r < n) ? in[4 * g + r < n ? 4 * g + r : 0] : 0.0f;
+                *reinterpret_cast<f32x4*>(arr_ + k * TS + 4 * g) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < n; ++i) AT(arr_, k, i) = in[i];
+        }
+    };
 
     float* Xg = a.X + (size_t)b * (N + 1) * NX;
     float* Ug = a.U + (size_t)b * N * NU;
@@ -607,9 +653,9 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
         const bool one_stage_per_lane = N <= 64;
         // step <- step + ap (new step - step), both trajectories
         auto blend = [&](float ap) {
-            batched<10>(NX * NS, lane, [&](int i) { const float d = dX[i]; return d + ap * (dXp[i] - d); },
+            batched<10>(SA_.nX, lane, [&](int i) { const float d = dX[i]; return __builtin_fmaf(ap, dXp[i] - d, d); },
                         [&](int i, float v) { dX[i] = v; });
-            batched<10>(NU * NS, lane, [&](int i) { const float d = dU[i]; return d + ap * (dUp[i] - d); },
+            batched<10>(SA_.nU, lane, [&](int i) { const float d = dU[i]; return __builtin_fmaf(ap, dUp[i] - d, d); },
                         [&](int i, float v) { dU[i] = v; });
         };
         for (int ii = 0; ii < n_sweeps; ++ii) {
@@ -623,19 +669,20 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                 if (ii == 0 || !one_stage_per_lane)
                 for (int k = lane; k < N; k += 64) {
                     const unsigned am = actm[k];
-                    float uk[NU], gk[NG];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) uk[i] = AT(Us, k, i);
+                    float uk[NU], gk[NG], sk[NG], lk[NG];
+                    ld_row(Us, k, uk);
+                    ld_row(sv, k, sk);
+                    ld_row(lv, k, lk);
                     M::gdot(a.mp, uk, gk);
 #pragma unroll
                     for (int j = 0; j < NG; ++j) {
                         const bool on = (am >> j) & 1u;
-                        const float s = AT(sv, k, j), l = AT(lv, k, j), cj = gk[j] - M::h(a.mp, j);
+                        const float s = sk[j], l = lk[j], cj = gk[j] - M::h(a.mp, j);
                         const float is = fast_rcp(s);
                         const float D = l * is;
                         const float rs = __builtin_amdgcn_rsqf(D);
                         gsq[k * TS + j] = on ? D * rs : 0.0f;
-                        gvt[k * TS + j] = on ? (tau * is + l + D * cj) * rs : 0.0f;
+                        gvt[k * TS + j] = on ? __builtin_fmaf(D, cj, __builtin_fmaf(tau, is, l)) * rs : 0.0f;
                     }
                 }
                 phase_sync();
@@ -832,8 +879,8 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
             // row of this lane in the image of stage 0, as a byte offset from the workspace base
             unsigned rowoff = 4u * (unsigned)((is_x ? wl.Ct : wl.Kt) + (is_x ? lane : is_u ? lane - 16 : 0) * TS);
             const unsigned rowstep = 4u * (is_x ? G::C_FLOATS : G::K_FLOATS);
-            float* dst = is_x ? (oX + lane * NS + 1) : is_u ? (oU + (lane - 16) * NS) : idle_sink;
-            const int dstep = (is_x || is_u) ? 1 : 0;
+            float* dst = is_x ? &AT(oX, 1, lane) : is_u ? &AT(oU, 0, lane - 16) : idle_sink;
+            const int dstep = (is_x || is_u) ? (LEAN ? TS : 1) : 0;
             // the used floats of a row: quad 0 (three states and the homogeneous slot) as a 16 B load,
             // the other quads as 12 B loads (a load with dead elements lets the allocator reuse them at
             // once -- which means a wait on the load in flight)
@@ -891,8 +938,15 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                 const bool live = lane < N;
                 const int k = live ? lane : 0;
                 float du[NU], g[NG], uk[NU], cc[NG], s[NG], l[NG], ds[NG], dl[NG];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { du[i] = AT(dUp, k, i); uk[i] = AT(Us, k, i); }
+                ld_row(dUp, k, du);
+                ld_row(Us, k, uk);
+                ld_row(sv, k, s);
+                ld_row(lv, k, l);
+                // lean variant: the blend of the step with the new one rides in this phase (the stage's rows, requested
+                // here, used once the step length is known) instead of two element-wise passes over the workspace
+                const int kx = (lane <= N) ? lane : 0;
+                float dxo[LEAN ? NX : 1], dxn[LEAN ? NX : 1], duo[LEAN ? NU : 1];
+                if constexpr (LEAN) { ld_row(dX, kx, dxo); ld_row(dXp, kx, dxn); ld_row(dU, k, duo); }
                 M::gdot(a.mp, du, g);
                 M::gdot(a.mp, uk, cc);          // c = G u - h at the linearisation point
                 const unsigned am = live ? actm[k] : 0u;
@@ -900,10 +954,9 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     cc[j] -= M::h(a.mp, j);
-                    s[j] = AT(sv, k, j); l[j] = AT(lv, k, j);
                     const float is = fast_rcp(s[j]);
                     ds[j] = -(g[j] + cc[j]) - s[j];
-                    dl[j] = tau * is - l[j] - l[j] * is * ds[j];
+                    dl[j] = __builtin_fmaf(-(l[j] * is), ds[j], __builtin_fmaf(tau, is, -l[j]));
                     const bool on = (am >> j) & 1u;
                     rp = on ? fmaxf(rp, -ds[j] * is) : rp;
                     rd = on ? fmaxf(rd, -dl[j] * __builtin_amdgcn_rcpf(l[j])) : rd;
@@ -915,13 +968,26 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     const bool on = (am >> j) & 1u;
-                    s[j] += on ? ap * ds[j] : 0.0f;
-                    l[j] += on ? ad * dl[j] : 0.0f;
-                    if (live) { AT(sv, k, j) = s[j]; AT(lv, k, j) = l[j]; }
-                    m_l += on ? s[j] * l[j] : 0.0f;
+                    s[j] = on ? __builtin_fmaf(ap, ds[j], s[j]) : s[j];
+                    l[j] = on ? __builtin_fmaf(ad, dl[j], l[j]) : l[j];
+                    m_l = on ? __builtin_fmaf(s[j], l[j], m_l) : m_l;
                 }
+                if (live) { st_row(sv, k, s); st_row(lv, k, l); }
                 mu_sum = wave_sum(m_l);
-                blend(ap);
+                if constexpr (LEAN) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) dxo[i] = __builtin_fmaf(ap, dxn[i] - dxo[i], dxo[i]);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) duo[i] = __builtin_fmaf(ap, du[i] - duo[i], duo[i]);
+                    if (lane <= N) st_row(dX, kx, dxo);
+                    if (live) st_row(dU, k, duo);
+                    if (N == 64 && lane < NX) {            // node 64 has no lane of its own
+                        const float d = AT(dX, 64, lane);
+                        AT(dX, 64, lane) = __builtin_fmaf(ap, AT(dXp, 64, lane) - d, d);
+                    }
+                } else {
+                    blend(ap);
+                }
                 if (ii + 1 < n_sweeps && live) {
                     const float tau_n = fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min);
                     float sq[NG], vt[NG];
@@ -932,7 +998,7 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                         const float D = l[j] * is;
                         const float rs = __builtin_amdgcn_rsqf(D);
                         sq[j] = on ? D * rs : 0.0f;
-                        vt[j] = on ? (tau_n * is + l[j] + D * cc[j]) * rs : 0.0f;
+                        vt[j] = on ? __builtin_fmaf(D, cc[j], __builtin_fmaf(tau_n, is, l[j])) * rs : 0.0f;
                     }
 #pragma unroll
                     for (int j = 0; j < NG; ++j) { gsq[k * TS + j] = sq[j]; gvt[k * TS + j] = vt[j]; }
@@ -947,7 +1013,7 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                     s = AT(sv, k, j); l = AT(lv, k, j);
                     const float is = fast_rcp(s);
                     dsj = -(g[j] + cc[j]) - s;
-                    dlj = tau * is - l - l * is * dsj;
+                    dlj = __builtin_fmaf(-(l * is), dsj, __builtin_fmaf(tau, is, -l));
                 };
                 for (int k = lane; k < N; k += 64) {
                     float du[NU], g[NG], uk[NU], cc[NG];
@@ -983,11 +1049,11 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                         float s, l, dsj, dlj;
                         step_dir(k, j, g, cc, s, l, dsj, dlj);
                         const bool on = (am >> j) & 1u;
-                        s += on ? ap * dsj : 0.0f;
-                        l += on ? ad * dlj : 0.0f;
+                        s = on ? __builtin_fmaf(ap, dsj, s) : s;
+                        l = on ? __builtin_fmaf(ad, dlj, l) : l;
                         AT(sv, k, j) = s;
                         AT(lv, k, j) = l;
-                        if (on) m_l += s * l;
+                        if (on) m_l = __builtin_fmaf(s, l, m_l);
                     }
                 }
                 mu_sum = wave_sum(m_l);
@@ -1003,8 +1069,8 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
             bad_l = bad_l || !(fabsf(v) <= 1e30f);
             sn_l = fmaxf(sn_l, fabsf(v));
         };
-        batched<10>(NX * NS, lane, [&](int i) { return dX[i]; }, step_norm);
-        batched<10>(NU * NS, lane, [&](int i) { return dU[i]; }, step_norm);
+        batched<10>(SA_.nX, lane, [&](int i) { return dX[i]; }, step_norm);
+        batched<10>(SA_.nU, lane, [&](int i) { return dU[i]; }, step_norm);
         stepn = wave_max(sn_l);
         const bool bad = __any(bad_l);
         if (bad) { status = NMPC_STATUS_NAN; finished = true; }
@@ -1016,9 +1082,9 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                 for (int k = lane; k < N; k += 64) {
                     float x[NX], u[NU], xn[NX], p[NP > 0 ? NP : 1];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) x[i] = AT(Xs, k, i) + al * AT(dX, k, i);
+                    for (int i = 0; i < NX; ++i) x[i] = __builtin_fmaf(al, AT(dX, k, i), AT(Xs, k, i));
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) u[i] = AT(Us, k, i) + al * AT(dU, k, i);
+                    for (int i = 0; i < NU; ++i) u[i] = __builtin_fmaf(al, AT(dU, k, i), AT(Us, k, i));
 #pragma unroll
                     for (int i = 0; i < NP; ++i) p[i] = pg[(size_t)k * NP + i];
                     M::step(a.mp, x, u, p, xn);
@@ -1028,7 +1094,7 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                     for (int i = 0; i < NX; ++i) {
                         const float e = x[i] - yk[i];
                         cst += 0.5f * a.W[i] * e * e;
-                        viol += fabsf(xn[i] - (AT(Xs, k + 1, i) + al * AT(dX, k + 1, i)));
+                        viol += fabsf(xn[i] - __builtin_fmaf(al, AT(dX, k + 1, i), AT(Xs, k + 1, i)));
                     }
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
@@ -1046,10 +1112,10 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
                     m_l += cst + a.rho * viol;
                 }
                 if (lane < NX) {
-                    const float xe = AT(Xs, N, lane) + al * AT(dX, N, lane);
+                    const float xe = __builtin_fmaf(al, AT(dX, N, lane), AT(Xs, N, lane));
                     const float e = xe - yre[lane];
                     m_l += 0.5f * a.We[lane] * e * e;
-                    m_l += a.rho * fabsf(x0[lane] - (AT(Xs, 0, lane) + al * AT(dX, 0, lane)));
+                    m_l += a.rho * fabsf(x0[lane] - __builtin_fmaf(al, AT(dX, 0, lane), AT(Xs, 0, lane)));
                 }
                 return wave_sum(m_l);
             };
@@ -1061,8 +1127,8 @@ __global__ __launch_bounds__(64, LEAN ? 2 : NMPC_RES_WAVES) void nmpc_qp_kernel(
             }
         }
         if (!bad) {
-            batched<10>(NX * NS, lane, [&](int i) { return Xs[i] + alpha * dX[i]; }, [&](int i, float v) { Xs[i] = v; });
-            batched<10>(NU * NS, lane, [&](int i) { return Us[i] + alpha * dU[i]; }, [&](int i, float v) { Us[i] = v; });
+            batched<10>(SA_.nX, lane, [&](int i) { return __builtin_fmaf(alpha, dX[i], Xs[i]); }, [&](int i, float v) { Xs[i] = v; });
+            batched<10>(SA_.nU, lane, [&](int i) { return __builtin_fmaf(alpha, dU[i], Us[i]); }, [&](int i, float v) { Us[i] = v; });
             phase_sync();
             if (!qp_ok) { status = NMPC_STATUS_QP; finished = true; }
             else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }

@@ -122,7 +122,7 @@ def _scipy_wholebody_nlp(o, w, b, N):
 
     z0 = np.concatenate([w.X[b, 1:N + 1].ravel(), w.U[b, :N].ravel()]).astype(float)
     r = minimize(cost, z0, method="SLSQP", constraints=[dict(type="eq", fun=defects), dict(type="ineq", fun=ineq)],
-                 options=dict(maxiter=400, ftol=1e-13))
+                 options=dict(maxiter=1500, ftol=1e-13))
     assert r.success, r.message
     return unpack(r.x)
 

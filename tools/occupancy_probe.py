@@ -10,7 +10,10 @@ import torch
 from iterative_learning_nmpc_amd import workloads as wl
 from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
 
-for N, B in ((20, 1024), (20, 8192), (50, 1024), (50, 8192)):
+cases = ((20, 1024), (20, 8192), (50, 1024), (50, 8192))
+if len(sys.argv) > 1:      # N:B pairs on the command line
+    cases = tuple(tuple(int(v) for v in a.split(':')) for a in sys.argv[1:])
+for N, B in cases:
     w = wl.centroidal_trot(B=B, N=N, seed=0)
     s = BatchedNmpcSolver(w.model_id, w.N, B, "cuda:0")
     s.set_model_params(w.mp)
@@ -28,5 +31,5 @@ for N, B in ((20, 1024), (20, 8192), (50, 1024), (50, 8192)):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 40
-    print(f"{os.environ.get('NMPC_HIP_LIB', 'default')}: N={N} B={B}: {ms:.4f} ms per call, {B / ms * 1e3 / 1e6:.3f} M solves/s, "
+    print(f"{os.environ.get('NMPC_HIP_LIB', 'default')} variant={os.environ.get('NMPC_QP_VARIANT', 'auto')}: N={N} B={B}: {ms:.4f} ms per call, {B / ms * 1e3 / 1e6:.3f} M solves/s, "
           f"{B * N / ms * 1e3 / 1e6:.1f} M stages/s", flush=True)
