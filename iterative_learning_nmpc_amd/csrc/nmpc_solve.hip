@@ -247,7 +247,7 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 //       kept for horizons whose resident layout does not fit the LDS and as NMPC_QP_VARIANT=lean.
 template <class M, bool LEAN>
 struct Lds {
-    int arr, qv, rv, gsq, gvt, act, umk, conv, total;   // float offsets
+    int arr, qv, rv, gsq, gvt, act, umk, conv, dx0, total;   // float offsets
     __host__ __device__ explicit Lds(int N) {
         const int NS = (N + 1) | 1;
         int o = 0;
@@ -261,6 +261,7 @@ struct Lds {
         act = o; o += round4(NS);
         umk = o; o += round4(NS);
         conv = o; o += CONV_FLOATS;
+        dx0 = o; o += LEAN ? TS : 0;              // lean: x0 - X[0], read at the start of every forward sweep
         total = o;
     }
 };
@@ -591,6 +592,10 @@ void nmpc_qp_kernel(const SolveArgs a) {
         drain(n_u, base, vr, put_r);
         drain(n_c, base, vc, put_c);
     }
+    float* dx0s = smem + L.dx0;
+    if constexpr (LEAN) {
+        if (lane < NX) dx0s[lane] = x0[lane] - Xg[lane];      // node 0 is a fixed point of the shift map
+    }
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
     for (int k = lane; k <= N; k += 64) {
@@ -641,6 +646,10 @@ void nmpc_qp_kernel(const SolveArgs a) {
     bool finished = false;
     STAMP_DECL;
     float cost = 0.0f, stepn = 0.0f, alpha = 1.0f;
+    // phase S of the lean variant with one node per lane (see there): the node's rows of X, U in registers
+    const bool rows_in_regs = LEAN && N < 64;
+    const int kx_s = lane <= N ? lane : 0, ku_s = lane < N ? lane : 0;
+    float xr[LEAN ? NX : 1], ur[LEAN ? NU : 1];
     {
         cost = wave_sum(cost_l);
         const int n_act = (int)(wave_sum((float)nact_l) + 0.5f);
@@ -871,9 +880,15 @@ void nmpc_qp_kernel(const SolveArgs a) {
             float* oX = use_ipm ? dXp : dX;
             float* oU = use_ipm ? dUp : dU;
             float vs[NX];
+            if constexpr (LEAN) {      // (the same difference, kept in the LDS: X lives in the workspace)
 #pragma unroll
-            for (int i = 0; i < NX; ++i) vs[i] = x0[i] - AT(Xs, 0, i);
-            if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
+                for (int i = 0; i < NX; ++i) vs[i] = dx0s[i];
+                if (lane < NX) AT(oX, 0, lane) = dx0s[lane];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) vs[i] = x0[i] - AT(Xs, 0, i);
+                if (lane < NX) AT(oX, 0, lane) = x0[lane] - AT(Xs, 0, lane);
+            }
             constexpr int FWD_PF = 4, RQ4 = slot_of(NX - 1) / 4 + 1;
             const bool is_x = lane < NX, is_u = (lane >= 16 && lane < 16 + NU);
             // row of this lane in the image of stage 0, as a byte offset from the workspace base
@@ -1069,8 +1084,22 @@ void nmpc_qp_kernel(const SolveArgs a) {
             bad_l = bad_l || !(fabsf(v) <= 1e30f);
             sn_l = fmaxf(sn_l, fabsf(v));
         };
-        batched<10>(SA_.nX, lane, [&](int i) { return dX[i]; }, step_norm);
-        batched<10>(SA_.nU, lane, [&](int i) { return dU[i]; }, step_norm);
+        // lean variant, one node per lane: the node's rows go through registers once -- norm, step and the store to the
+        // caller's X, U -- instead of six element-wise passes over the workspace (each a memory round trip)
+        float dxr[LEAN ? NX : 1], dur[LEAN ? NU : 1];
+        if constexpr (LEAN) {
+            if (rows_in_regs) {
+                ld_row(dX, kx_s, dxr); ld_row(Xs, kx_s, xr); ld_row(dU, ku_s, dur); ld_row(Us, ku_s, ur);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) step_norm(0, lane <= N ? dxr[i] : 0.0f);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) step_norm(0, lane < N ? dur[i] : 0.0f);
+            }
+        }
+        if (!rows_in_regs) {
+            batched<10>(SA_.nX, lane, [&](int i) { return dX[i]; }, step_norm);
+            batched<10>(SA_.nU, lane, [&](int i) { return dU[i]; }, step_norm);
+        }
         stepn = wave_max(sn_l);
         const bool bad = __any(bad_l);
         if (bad) { status = NMPC_STATUS_NAN; finished = true; }
@@ -1127,9 +1156,18 @@ void nmpc_qp_kernel(const SolveArgs a) {
             }
         }
         if (!bad) {
-            batched<10>(SA_.nX, lane, [&](int i) { return __builtin_fmaf(alpha, dX[i], Xs[i]); }, [&](int i, float v) { Xs[i] = v; });
-            batched<10>(SA_.nU, lane, [&](int i) { return __builtin_fmaf(alpha, dU[i], Us[i]); }, [&](int i, float v) { Us[i] = v; });
-            phase_sync();
+            if (rows_in_regs) {
+                if constexpr (LEAN) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xr[i] = __builtin_fmaf(alpha, dxr[i], xr[i]);
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) ur[i] = __builtin_fmaf(alpha, dur[i], ur[i]);
+                }
+            } else {
+                batched<10>(SA_.nX, lane, [&](int i) { return __builtin_fmaf(alpha, dX[i], Xs[i]); }, [&](int i, float v) { Xs[i] = v; });
+                batched<10>(SA_.nU, lane, [&](int i) { return __builtin_fmaf(alpha, dU[i], Us[i]); }, [&](int i, float v) { Us[i] = v; });
+                phase_sync();
+            }
             if (!qp_ok) { status = NMPC_STATUS_QP; finished = true; }
             else if (a.nlp_tol > 0.0f && stepn < a.nlp_tol) { status = NMPC_STATUS_OK; finished = true; }
         }
@@ -1138,10 +1176,23 @@ void nmpc_qp_kernel(const SolveArgs a) {
     // first iteration, is the SHIFTED previous solution: it is written back so that the caller's node bookkeeping
     // (last_node already advanced) and the trajectory stay aligned
     if (status != NMPC_STATUS_NAN || a.shift > 0) {
-        batched<10>((N + 1) * NX, lane, [&](int e) { const int k = e / NX; return AT(Xs, k, e - k * NX); },
-                    [&](int e, float v) { Xg[e] = v; });
-        batched<10>(N * NU, lane, [&](int e) { const int k = e / NU; return AT(Us, k, e - k * NU); },
-                    [&](int e, float v) { Ug[e] = v; });
+        if (rows_in_regs) {
+            if constexpr (LEAN) {
+                if (lane <= N) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) Xg[lane * NX + i] = xr[i];
+                }
+                if (lane < N) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) Ug[lane * NU + i] = ur[i];
+                }
+            }
+        } else {
+            batched<10>((N + 1) * NX, lane, [&](int e) { const int k = e / NX; return AT(Xs, k, e - k * NX); },
+                        [&](int e, float v) { Xg[e] = v; });
+            batched<10>(N * NU, lane, [&](int e) { const int k = e / NU; return AT(Us, k, e - k * NU); },
+                        [&](int e, float v) { Ug[e] = v; });
+        }
     }
     STAMP(5);
 #ifdef NMPC_STAMPS
