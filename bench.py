@@ -503,6 +503,30 @@ def main():
                 "failed_problems": int((status == 1).sum().item() + (status == 4).sum().item())}
         s.set_max_iter(a.sqp)
 
+    # the same step at eight times the batch (the per-GPU size of configs[3]): beyond one problem per SIMD the QP kernel
+    # runs its two-waves-per-SIMD variant; inputs are the batch above, repeated.  Reported next to the
+    # headline, not as it.
+    large = None
+    if not wbm and B == 1024 and a.sqp == 1 and a.precision == 0 and not a.no_cold_start:
+        BL = 8 * B
+        sl = BatchedNmpcSolver(w.model_id, N, BL, dev)
+        sl.set_model_params(w.mp)
+        sl.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+        sl.set_max_iter(a.sqp)
+        sl.set_max_qp_iter(a.ipm)
+        tl = {k: sl.to_device(np.concatenate([getattr(w, k)] * 8)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+        stl = torch.empty(BL, dtype=torch.int32, device=dev)
+        n_large = max(2, min(20, a.steps))
+        for i in range(n_large + 3):
+            if i == 3:
+                torch.cuda.synchronize(); tc = time.perf_counter()
+            sl.solve(tl["x0"], tl["yref"], tl["yref_e"], tl["params"], tl["X"], tl["U"], stl, None, shift=1)
+        torch.cuda.synchronize()
+        ms_large = (time.perf_counter() - tc) / n_large * 1e3
+        large = {"batch": BL, "ms_per_step": ms_large, "solves_per_s_per_gpu": BL / (ms_large * 1e-3),
+                 "failed_problems": int((stl == 1).sum().item() + (stl == 4).sum().item())}
+        del sl, tl
+
     if rank == 0:
         n_sweeps = a.ipm if a.ipm > 0 else 1
         flops, nbytes = (algorithmic_work_wholebody(N, n_sweeps) if wbm else
@@ -546,7 +570,7 @@ def main():
                          "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                          "binds": "instruction issue of one wave per SIMD along the serial stage recursion (MFMA + VALU + LDS of a wave "
                                   "do not overlap; profiles/): neither HBM nor the MFMA peak"},
-            "failed_problems": bad, "cold_start": cold,
+            "failed_problems": bad, "cold_start": cold, "large_batch": large,
         }
         if world > 1 and ag_ev:
             out["allgather"] = {"ms": float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in ag_ev])), "backend": dist.get_backend(),

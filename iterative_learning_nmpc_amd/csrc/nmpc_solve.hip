@@ -15,7 +15,7 @@
 // through AGPR<->VGPR copies and pinned the kernel at one wave per SIMD).
 // Stage matrices A~, B~, K~, Acl~ live in an HBM/L2 workspace as compact images (640-768 B);
 // trajectories, gradients and IPM state of a problem live in LDS (39.6 KB at N = 50) inside
-// nmpc_qp_kernel -- or, in its lean variant for large batches, partly in the workspace (Lds).
+// nmpc_qp_kernel -- or, in its lean variant for batches beyond one wave per SIMD, partly in the workspace (Lds).
 // Kernel variants (template flags): LDS layout, precision of the barrier product, set of contact
 // patterns with a static stage body.  DESIGN.md 5 has the measurements behind each choice.
 #include <hip/hip_runtime.h>
@@ -241,10 +241,11 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 
 // LDS layout of one problem.  Two variants of the QP kernel:
 //   resident (LEAN = false): stage arrays + sweep operands + conversion tiles, 39.6 KB at N = 50 ->
-//       4 waves per CU, one per SIMD, larger batches in rounds: the default at every batch size;
-//   lean (LEAN = true): the stage arrays live in the workspace, 18.4 KB -> 8 waves per CU, two per SIMD.
-//       Slower since the resident kernel got the register budget of one wave per SIMD;
-//       kept for horizons whose resident layout does not fit the LDS and as NMPC_QP_VARIANT=lean.
+//       4 waves per CU, one per SIMD: the choice while the batch fits that many waves (B <= 1024 on an MI355X);
+//   lean (LEAN = true): the stage arrays live in the workspace (stage-major rows), 17.8 KB -> 8 waves per CU, two per
+//       SIMD: the choice for larger batches (the second wave fills the first one's dependency stalls: 2.75 M solves/s
+//       at B = 8192 against 2.30 M), for horizons whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
+// Same arithmetic in the same order: results are bit-identical (tests/test_gpu_parity.py).  DESIGN.md 7.
 template <class M, bool LEAN>
 struct Lds {
     int arr, qv, rv, gsq, gvt, act, umk, conv, dx0, total;   // float offsets
@@ -431,12 +432,12 @@ __device__ __forceinline__ void batched(int n, int lane, Load&& ld, Store&& st) 
 // otherwise over the model's short list (common_variant) with the run-time fallback for the rest.
 // Two kernels rather than one loop with everything: measured, the mere presence of the other
 // variants in the kernel costs the common ones 2.5 % (code layout, register allocation).
-// Registers: the resident variant runs one wave per SIMD and is compiled for that (second launch-bound
-// = waves per SIMD), so the values that do not fit into 256 VGPRs (35 in this build: profiles/r02_isa_resources.md) spill into AGPRs -- one
-// v_accvgpr move each -- instead of scratch memory, whose reloads sat in the interior-point update behind a
-// vmcnt(0) each (measured: -6 % per solve call).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs
-// keep their VGPR operands (with AGPRs available the compiler otherwise moves the accumulators there and
-// copies them back and forth: slower).  The lean variant needs two waves per SIMD and has no AGPRs left.
+// Registers: 234 VGPRs (resident) / 256 with 16 values in scratch, none of them in a stage loop (lean); no AGPRs
+// (profiles/r02_isa_resources.md).  The resident variant is pinned to ONE wave per SIMD (amdgpu_waves_per_eu): its LDS image lets
+// four waves onto a CU, and with two allowed per SIMD the hardware co-locates them and leaves SIMDs idle once a batch runs in
+// rounds (measured 1.91 M instead of 2.30 M solves/s at B = 8192).  build.sh passes -amdgpu-mfma-vgpr-form so that the MFMAs keep
+// their VGPR operands.  What kept both variants above 256 registers until round 2 was the interior-point phase, not the sweeps:
+// its loads were interleaved with their uses; a stage's rows are now requested up front (ld_row / st_row).
 // Floating-point contraction is OFF in the body of this kernel (the tile algebra in nmpc_sweep.hpp / nmpc_tile.hpp is MFMA and
 // explicit fma; this is about the lane = stage arithmetic) and every a*b + c that is meant as one operation is written as fmaf:
 // left to the compiler, which products get fused into the following add depends on the instantiation -- the resident and the

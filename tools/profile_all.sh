@@ -1,10 +1,11 @@
 #!/usr/bin/env bash
-# Round profiles (run on the GPU box through gpurun): kernel trace + PMC passes of the headline, the whole-body workload,
+# Round profiles (run on the GPU box through gpurun): kernel trace + PMC passes of the headline, the same at B = 8192 (two waves per SIMD), the whole-body workload,
 # its mixed-precision variant, and a kernel trace of the rollout mode.  Summaries -> profiles/ by tools/summarize_profile.py.
 set -uo pipefail
 tag="${1:-r02}"
 export TMPDIR=/tmp
 bash tools/profile.sh ${tag}_c
+bash tools/profile.sh ${tag}_c8k --batch 8192
 bash tools/profile.sh ${tag}_wb --workload wholebody --steps 5 --warmup 1
 bash tools/profile.sh ${tag}_wbp1 --workload wholebody --precision 1 --steps 5 --warmup 1
 mkdir -p gpurun_out/prof_${tag}_roll
