@@ -38,8 +38,9 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 // VEC = false: loads are guarded element-wise (K = 47, N = 12 ... are not tile multiples; rows of X
 // are not 16 B aligned).  VEC = true (M, N multiples of 64, K of 16, leading dimensions multiples of
 // 4): 16 B global loads without guards.  gridDim.z > 1 splits K (the weight-gradient GEMMs contract over the
-// batch and have few output tiles: 64 at hidden = 512, 8 for the input and output layers): the
-// partial products are added to C with float atomics, C zeroed by the caller.
+// batch and have few output tiles: 64 at hidden = 512, 8 for the input and output layers): every split writes
+// its partial product to split_part[z][M][N], split_reduce_kernel adds them up in split order -- no float
+// atomics, so a training step is reproducible run to run (as the database statistics are).
 constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
 
 // The K loop advances KS slices at a time: their 2 x KS 16 B loads per thread are issued together one
@@ -50,7 +51,7 @@ constexpr int KS = 4;
 template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                    const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                   int ldc, const float* __restrict__ bias) {
+                                                   int ldc, const float* __restrict__ bias, float* __restrict__ split_part) {
     __shared__ __attribute__((aligned(16))) float As[KS][BM * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[KS][BN * LDT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     // K range of this block: whole slices of BK per split (the last split may be short or empty)
     const int kper = (((K + (int)gridDim.z - 1) / (int)gridDim.z) + BK - 1) / BK * BK;
     const int kbeg = blockIdx.z * kper, kend = kbeg + kper < K ? kbeg + kper : K;
-    if (kbeg >= kend) return;                                     // an empty split (block-uniform)
+    const bool empty_split = kbeg >= kend;                        // block-uniform: an empty split contributes zeros
+    if (empty_split && gridDim.z == 1) return;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm + 8 * (r >> 2) + 4 * h + (r & 3);
             if (m < M) {
-                if (gridDim.z > 1) atomicAdd(C + (size_t)m * ldc + n, acc[r]);
+                if (gridDim.z > 1) split_part[((size_t)blockIdx.z * M + m) * N + n] = acc[r];     // summed in split order below
                 else C[(size_t)m * ldc + n] = acc[r] + bv;
             }
         }
@@ -506,6 +508,7 @@ struct Policy {
     float *part = nullptr;     // partial column sums [2][RCHUNK][max(hidden, n_out)]
     float *part_b = nullptr;   // partial bias-gradient sums of the hidden layers [L][RCHUNK][hidden]
     float *loss_part = nullptr;   // per-block partial losses of l1_kernel
+    float *split_ws = nullptr;    // partial products of the split-K weight-gradient GEMMs [splits][M][N]
     float *sign_count = nullptr;  // int[n_out]: l1_kernel's sign counts (allocated and zeroed with the float buffers)
     bool grad_dirty = false;   // a step that did not reach adam_kernel left grad non-zero
     long long step = 0;
@@ -522,17 +525,34 @@ int pfail(Policy* p, int code, const std::string& msg) {
         if (e_ != hipSuccess) return pfail(p, NMPC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// split_k > 1: C must be zero on entry (partial products are added with atomics); no bias then
+// C[m][n] = sum over the splits, in split order (deterministic)
+__global__ __launch_bounds__(256) void split_reduce_kernel(int M, int N, int splits, const float* __restrict__ part,
+                                                           float* __restrict__ C, int ldc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    float acc = 0.0f;
+    for (int z = 0; z < splits; ++z) acc += part[(size_t)z * M * N + i];
+    const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+    C[(size_t)m * ldc + n] = acc;
+}
+
+constexpr size_t SPLIT_WS_FLOATS = (size_t)256 * BM * BN;     // at most 255 blocks of 64 x 64 take part in a split GEMM
+
+// split_k > 1: partial products go through split_ws (SPLIT_WS_FLOATS) and are summed in split order; no bias then
 template <bool TA, bool TB>
 void gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-          const float* bias, int split_k = 1) {
+          const float* bias, int split_k = 1, float* split_ws = nullptr) {
     const bool aligned = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (reinterpret_cast<uintptr_t>(B) % 16 == 0);
     const bool vec = aligned && M % BM == 0 && N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
     // more splits for GEMMs with very few output tiles
     while (split_k > 1 && grid.x * grid.y * grid.z < 128 && (int)grid.z * 2 * BK <= K) grid.z *= 2;
-    if (vec) hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
-    else hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias);
+    while (grid.z > 1 && (split_ws == nullptr || (size_t)grid.z * M * N > SPLIT_WS_FLOATS)) grid.z /= 2;
+    if (vec) hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, split_ws);
+    else hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, bias, split_ws);
+    if (grid.z > 1)
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, st, M, N, (int)grid.z,
+                           split_ws, C, ldc);
 }
 
 constexpr int SPLIT_K = 4;    // of the weight-gradient GEMMs (contraction over the batch, 64 output tiles at hidden = 512)
@@ -610,7 +630,7 @@ int nmpc_policy_create(const nmpc_policy_dims* dims, int device_id, void** handl
         {&p->pred, Bm * dims->n_out}, {&p->dpred, Bm * dims->n_out},
         {&p->part, (size_t)2 * RCHUNK * (size_t)(H > dims->n_out ? H : dims->n_out)},
         {&p->part_b, (size_t)L * RCHUNK * H}, {&p->loss_part, (Bm * dims->n_out + 255) / 256 + 1},
-        {&p->sign_count, (size_t)dims->n_out}};
+        {&p->sign_count, (size_t)dims->n_out}, {&p->split_ws, SPLIT_WS_FLOATS}};
     nmpc::DeviceGuard guard(device_id);
     hipError_t e = guard.err;
     for (auto& b : bufs) {
@@ -632,7 +652,7 @@ void nmpc_policy_destroy(void* handle) {
     if (!p) return;
     nmpc::DeviceGuard guard(p->device);
     float* all[] = {p->theta, p->grad, p->m, p->v, p->run_mean, p->run_var, p->mu, p->inv, p->act, p->z,
-                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part, p->sign_count};
+                    p->dbuf[0], p->dbuf[1], p->pred, p->dpred, p->part, p->part_b, p->loss_part, p->sign_count, p->split_ws};
     for (float* q : all) if (q) (void)hipFree(q);
     delete p;
 }
@@ -721,7 +741,7 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
                        reinterpret_cast<int*>(p->sign_count));
     // output layer: dW = dP' a_L, db = colsum dP, d = dP W
     const float* aL = p->act + (size_t)(L - 1) * p->d.batch_max * H;
-    gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr, SPLIT_K);
+    gemm<true, true>(st, no, H, B, p->dpred, no, aL, H, p->grad + p->oW[L], H, nullptr, SPLIT_K, p->split_ws);
     float* d = p->dbuf[0];
     float* dn = p->dbuf[1];
     gemm<false, true>(st, B, H, no, p->dpred, no, p->theta + p->oW[L], H, d, H, nullptr);
@@ -740,7 +760,7 @@ int nmpc_policy_train_step(void* handle, int B, const float* X, const float* Y, 
         } else {
             hipLaunchKernelGGL(reduce_final_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, p->part, dbeta, (float*)nullptr);
         }
-        gemm<true, true>(st, H, fan_in, B, d, H, a, fan_in, p->grad + p->oW[l], fan_in, nullptr, SPLIT_K);
+        gemm<true, true>(st, H, fan_in, B, d, H, a, fan_in, p->grad + p->oW[l], fan_in, nullptr, SPLIT_K, p->split_ws);
         if (l > 0) {
             gemm<false, true>(st, B, H, H, d, H, p->theta + p->oW[l], H, dn, H, nullptr);
             float* t = d; d = dn; dn = t;

@@ -100,8 +100,10 @@ class DevicePolicy:
     def get_parameters(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         n_in, n_out, L, hidden, bn = self.dims
         theta = torch.empty(self.n_theta, dtype=torch.float32, device=self.device)
-        rm = torch.empty(L, hidden, dtype=torch.float32, device=self.device)
-        rv = torch.empty(L, hidden, dtype=torch.float32, device=self.device)
+        # (without BatchNorm there are no running statistics: the library leaves these two as they are -- zeros / ones,
+        #  the state of a fresh BatchNorm layer, rather than uninitialised memory)
+        rm = torch.zeros(L, hidden, dtype=torch.float32, device=self.device)
+        rv = torch.ones(L, hidden, dtype=torch.float32, device=self.device)
         self._check(self.lib.nmpc_policy_get_params(self._h, _ptr(theta), _ptr(rm), _ptr(rv), _stream(self.device)),
                     "nmpc_policy_get_params")
         return theta, rm, rv

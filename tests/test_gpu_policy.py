@@ -100,6 +100,23 @@ def test_policy_forward_and_train_step_match_oracle(n_in, n_out, L, hidden, bn, 
     assert rel(pol.forward(torch.tensor(X, dtype=torch.float32, device=dev)).cpu().numpy(), o.forward(X, train=False)) < 1e-2
 
 
+@pytest.mark.parametrize("n_in,n_out,L,hidden,bn,B", [(47, 12, 3, 512, True, 1000), (9, 4, 2, 65, False, 33)])
+def test_training_is_reproducible_run_to_run(n_in, n_out, L, hidden, bn, B):
+    """Five Adam steps from the same parameters on the same batches, twice: parameters, running statistics and losses
+    agree bit for bit (the split-K weight-gradient GEMMs sum their partial products in split order, no float atomics)."""
+    rng = np.random.default_rng(11)
+    X = torch.tensor(rng.standard_normal((5, B, n_in)), dtype=torch.float32, device="cuda:0")
+    Y = torch.tensor(rng.standard_normal((5, B, n_out)), dtype=torch.float32, device="cuda:0")
+    runs = []
+    for _ in range(2):
+        pol, _o = _pair(n_in, n_out, L, hidden, bn, batch_max=B)
+        losses = [pol.train_step(X[s], Y[s], 1e-3).item() for s in range(5)]
+        runs.append((losses, [t.cpu().numpy() for t in pol.get_parameters()]))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()), a.size)
+
+
 def test_policy_argument_errors():
     from iterative_learning_nmpc_amd import _lib
     from iterative_learning_nmpc_amd.policy import DevicePolicy
