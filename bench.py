@@ -507,7 +507,7 @@ def main():
     # runs its two-waves-per-SIMD variant; inputs are the batch above, repeated.  Reported next to the
     # headline, not as it.
     large = None
-    if not wbm and B == 1024 and a.sqp == 1 and a.precision == 0 and not a.no_cold_start:
+    if world == 1 and not wbm and B == 1024 and a.sqp == 1 and a.precision == 0 and not a.no_cold_start:
         BL = 8 * B
         sl = BatchedNmpcSolver(w.model_id, N, BL, dev)
         sl.set_model_params(w.mp)

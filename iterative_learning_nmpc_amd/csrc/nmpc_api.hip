@@ -29,7 +29,7 @@ struct Handle {
     float* dbg = nullptr;    // diagnostic builds only (nmpc_debug_set_buffer)
     float* roll = nullptr;   // rollout problem tensors: x0 alias, yref, yref_e, params (B_max sized)
     int n_cu = 256;          // compute units of the device
-    int force_variant = 0;   // NMPC_QP_VARIANT: 0 resident unless it does not fit the LDS, 1 resident, 2 lean (tests, tuning)
+    int force_variant = 0;   // NMPC_QP_VARIANT: 0 chosen per call by batch size and horizon (launch_solve), 1 resident, 2 lean (tests, tuning)
     int all_patterns = 0;    // nmpc_set_contact_patterns: 1 = kernel with a static stage body per contact pattern
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;

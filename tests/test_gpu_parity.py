@@ -447,14 +447,15 @@ def test_lean_variant_is_bit_identical_to_resident(dev, monkeypatch, model, N, o
 
 @pytest.mark.gpu
 def test_batch_beyond_one_wave_per_simd_runs_in_rounds(dev, oracle32, monkeypatch):
-    """B > 4 waves/CU x CUs: the resident kernel runs the batch in rounds; the result equals the forced-lean
-    one (two waves per SIMD) bit for bit and both match the oracle on the tail of the batch."""
+    """B > 4 waves/CU x CUs: the library's own choice (the two-waves-per-SIMD variant beyond one problem per SIMD) equals
+    the resident kernel forced onto the same batch, which runs it in rounds, bit for bit -- and both match the oracle on
+    the tail of the batch."""
     from iterative_learning_nmpc_amd import workloads as wl
     monkeypatch.delenv("NMPC_QP_VARIANT", raising=False)
     B = 1100
     w = wl.centroidal_trot(B=B, N=50, seed=17)
     X, U, st, _ = _gpu_solve(_solver(w, B, dev), w)
-    monkeypatch.setenv("NMPC_QP_VARIANT", "lean")
+    monkeypatch.setenv("NMPC_QP_VARIANT", "resident")
     Xr, Ur, str_, _ = _gpu_solve(_solver(w, B, dev), w)
     assert np.array_equal(X, Xr) and np.array_equal(U, Ur) and np.array_equal(st, str_)
     sel = slice(B - 24, B)                                    # the tail of the batch: the second round
