@@ -823,7 +823,7 @@ void nmpc_qp_kernel(const SolveArgs a) {
                     auto run = [&](auto mask_tag) {
                         constexpr unsigned MK = decltype(mask_tag)::value;
                         constexpr unsigned STEPS = (IPM && !BF16B && MK != DYNAMIC_MASK) ? M::barrier_steps(MK) : 0xFu;
-                        return backward_stage<NU, MK, true, ALLV, STEPS>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
+                        return backward_stage<NU, MK, true, ALLV, STEPS, LEAN ? 0 : 2>(P, A0, B0, T0, Qt, St, Rt, conv, sl, lane,
                                                                         cm & 0xFFFFu, Kk, Acl, sh SST_PASS);
                     };
                     bool ok = true;

@@ -42,6 +42,9 @@ struct SweepLane {
     // with all contact patterns spilled them (measured +1.3 % with the LDS copy there, -0.7 % here).
     const float* rs_free;
     float rs_free_s[16];
+    // identity columns of the in-register layout conversion (backward_stage): what lane rows 2, 3 (the identity and
+    // sink groups of the column layout) receive through the half swaps -- idx[r]: slots r and 8 + r, idy[r]: 4 + r, 12 + r
+    float idx[4], idy[4];
     // fills the identity tile as well: the caller orders it (wave_sync) before the first stage
     __device__ __forceinline__ void init(float* conv, int lane, int hx, const float* rs_free_values) {
         const int t = lane >> 4, c = lane & 15;
@@ -52,6 +55,11 @@ struct SweepLane {
         wb = ((t == 1) ? T1 : (t == 2) ? T0 : Td) + c * LDC;
         rd = ((t == 0) ? T0 : (t == 1) ? T1 : Ti) + c * LDC;
         hs_col = (c == HS) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            idx[r] = (c == (t < 2 ? r : 8 + r)) ? 1.0f : 0.0f;
+            idy[r] = (c == (t < 2 ? 4 + r : 12 + r)) ? 1.0f : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) corner[r] = (c == hx && 4 * t + r == hx);
         for (int i = lane; i < CTILE; i += 64) Ti[i] = (i % LDC == i / LDC) ? 1.0f : 0.0f;
@@ -71,6 +79,28 @@ __device__ __forceinline__ void xty_pair(f32x4 X0, f32x4 Y0, f32x4& C0, f32x4 X1
         C0 = mfma4(X0[i], Y0[i], C0);
         C1 = mfma4(X1[i], Y1[i], C1);
     }
+}
+
+// Half exchanges between lane rows (16 lanes each) of two registers -- gfx950's v_permlane16_swap / v_permlane32_swap:
+//   swap16(A, B): A.row1 <-> B.row0, A.row3 <-> B.row2        swap32(A, B): A.rows{2,3} <-> B.rows{0,1}
+// With them the layout changes around the elimination can stay in registers instead of going through the LDS (CONV):
+//   bit 0, accumulator layout -> column layout: register r of tiles T0 (Huu), T1 (H~ux) at lane row q is row 4q + r of
+//   column c; column register D[4q + r] wants T0's value in lane row 0 and T1's in lane row 1 (rows 2, 3: identity columns):
+//       swap16(T0[r], T1[r]) = X [t0_0 t1_0 t0_2 t1_2], Y [t0_1 t1_1 t0_3 t1_3];  swap32(X, idx) -> D[r], D[8 + r];
+//       swap32(Y, idy) -> D[4 + r], D[12 + r]
+//   bit 1, column layout -> accumulator layout (Y from lane row 1, W from lane row 2), a..d = D[r], D[4+r], D[8+r], D[12+r]:
+//       swap32(a, c), swap32(b, d), then swap16(a, b).second = Y[r] and swap16(c, d).first = W[r].
+// Measured (solves/s at B = 1024 one wave per SIMD / B = 8192 two waves): LDS both ways 2.20 M / 2.72 M; bit 0 alone 2.19 / 2.66;
+// bit 1 alone 2.25 / 2.70; both 2.22 / 2.63.  The first conversion's LDS latency hides behind the A~'P~A~ MFMAs and the swaps
+// are VALU time, which two waves per SIMD compete for; the second one is an exposed round trip that twelve swaps replace.  So:
+// CONV = 2 for the resident variant of the QP kernel, 0 (LDS) for the lean one and the dense LQ kernel.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
 }
 
 // One backward stage on the critical path:  P~_{k+1} -> P~_k, and the gain tiles of stage k.
@@ -94,7 +124,7 @@ __device__ __forceinline__ void xty_pair(f32x4 X0, f32x4 Y0, f32x4& C0, f32x4 X1
 // rows), so W and Y come back from the LDS with zero padding and need no masking.
 // Outputs (accumulator layout): K~ = -W'Y, Acl~ = A~ + B~K~  with  W = D^-1/2 L^-1,
 // Y = D^-1/2 L^-1 H~ux.  Returns false on a non-positive pivot.
-template <int NU, unsigned MASK, bool SLOT3, bool RSF_LDS, unsigned NEXT_STEPS = 0xFu, class NextCost>
+template <int NU, unsigned MASK, bool SLOT3, bool RSF_LDS, unsigned NEXT_STEPS = 0xFu, int CONV = 0, class NextCost>
 __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32x4 Bt, f32x4 Qt, f32x4 St,
                                                f32x4 Rt, float* conv, const SweepLane& sl, int lane,
                                                unsigned coupled, f32x4& Kout, f32x4& Aclout,
@@ -107,15 +137,25 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     f32x4 Hux = St, Huu = Rt;
     xty_pair<STEPS>(Ba, PA, Hux, Ba, PB, Huu);       // row HS of B~ is zero
     SST(0);
-    lds_store_acc(conv, lane, Huu);
-    lds_store_acc(conv + CTILE, lane, Hux);
-    wave_sync();
-
     // column layout: lane L -> column (L&15) of tile (L>>4): Huu | H~ux | I | I
     constexpr int NQ = SLOT3 ? slot_of(NU - 1) / 4 + 1 : (NU + 3) / 4;
-    f32x4 cq[NQ];
+    f32x4 cq[4];
+    if constexpr (!(CONV & 1)) {     // through the conversion tiles of the LDS
+        lds_store_acc(conv, lane, Huu);
+        lds_store_acc(conv + CTILE, lane, Hux);
+        wave_sync();
 #pragma unroll
-    for (int i4 = 0; i4 < NQ; ++i4) cq[i4] = *reinterpret_cast<const f32x4*>(sl.rd + 4 * i4);
+        for (int i4 = 0; i4 < NQ; ++i4) cq[i4] = *reinterpret_cast<const f32x4*>(sl.rd + 4 * i4);
+    } else {
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) {
+            float x = Huu[r], y = Hux[r], zx = sl.idx[r], zy = sl.idy[r];
+            swap16(x, y);
+            swap32(x, zx);
+            swap32(y, zy);
+            cq[0][r] = x; cq[1][r] = y; cq[2][r] = zx; cq[3][r] = zy;
+        }
+    }
     // scales of the uncoupled rows (static masks with such rows only)
     constexpr bool FREE_ROWS = RSF_LDS && (MASK != DYNAMIC_MASK) && ((~MASK & ((NU < 32) ? ((1u << NU) - 1u) : ~0u)) != 0u);
     f32x4 rq[(NU + 3) / 4];
@@ -154,22 +194,41 @@ __device__ __forceinline__ bool backward_stage(f32x4& P, f32x4 Aa, f32x4 Ba, f32
     nc.finish();
     const f32x4 Hxx = 0.5f * (H + Ht);
     SST(2);
-    wave_sync();
+    f32x4 Y = zero4(), W = zero4();
+    if constexpr (!(CONV & 2)) {
+        wave_sync();
 #pragma unroll
-    for (int i4 = 0; i4 < NQ; ++i4) {
-        f32x4 v;
+        for (int i4 = 0; i4 < NQ; ++i4) {
+            f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = SLOT3 ? 3 * i4 + r : 4 * i4 + r;
-            const bool used = (i < NU) && !(SLOT3 && r == 3);
-            v[r] = used ? col[used ? i : 0] : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                const int i = SLOT3 ? 3 * i4 + r : 4 * i4 + r;
+                const bool used = (i < NU) && !(SLOT3 && r == 3);
+                v[r] = used ? col[used ? i : 0] : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(sl.wb + 4 * i4) = v;
         }
-        *reinterpret_cast<f32x4*>(sl.wb + 4 * i4) = v;
+        wave_sync();
+        Y = lds_load_acc(conv + CTILE, lane);
+        W = lds_load_acc(conv, lane);
+        wave_sync();
+    } else {
+#pragma unroll
+        for (int r = 0; r < STEPS; ++r) {
+            float d4[4];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int i = SLOT3 ? 3 * i4 + r : 4 * i4 + r;
+                d4[i4] = (i4 < NQ && i < NU) ? col[(i4 < NQ && i < NU) ? i : 0] : 0.0f;
+            }
+            swap32(d4[0], d4[2]);
+            swap32(d4[1], d4[3]);
+            swap16(d4[0], d4[1]);
+            swap16(d4[2], d4[3]);
+            Y[r] = d4[1];
+            W[r] = d4[2];
+        }
     }
-    wave_sync();
-    const f32x4 Y = lds_load_acc(conv + CTILE, lane);
-    const f32x4 W = lds_load_acc(conv, lane);
-    wave_sync();
     SST(3);
     // P~+ = H~xx - Y'Y on two accumulators, interleaved with the chain of K~ = -W'Y
     const f32x4 nY = -Y;
