@@ -116,7 +116,7 @@ int launch_wb(Handle* h, nmpc::wb::WbArgs a, hipStream_t st) {
 // Two variants of the QP kernel (nmpc_solve.hip, Lds).  Resident: stage arrays in the LDS (39.6 KB at N = 50: four waves per CU),
 // pinned to one wave per SIMD -- the choice while the batch fits that many waves (B <= 4 x CUs: 2.2 M solves/s at B = 1024).
 // Lean: stage arrays in the workspace, 17.7 KB, two waves per SIMD -- the choice for larger batches, where the second wave fills
-// the first one's dependency stalls (2.65 M at B = 8192 against 2.31 M resident), for horizons whose resident layout does not
+// the first one's dependency stalls (2.7 M at B = 8192 against 2.3 M resident), for horizons whose resident layout does not
 // fit the LDS, and NMPC_QP_VARIANT=lean.  Both run the same arithmetic in the same order (bit-identical results, tested).
 template <class M, bool LEAN, bool BF16B, bool ALLV>
 int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks) {

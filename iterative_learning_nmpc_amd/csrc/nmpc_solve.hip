@@ -243,8 +243,8 @@ constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N
 //   resident (LEAN = false): stage arrays + sweep operands + conversion tiles, 39.6 KB at N = 50 ->
 //       4 waves per CU, one per SIMD: the choice while the batch fits that many waves (B <= 1024 on an MI355X);
 //   lean (LEAN = true): the stage arrays live in the workspace (stage-major rows), 17.8 KB -> 8 waves per CU, two per
-//       SIMD: the choice for larger batches (the second wave fills the first one's dependency stalls: 2.75 M solves/s
-//       at B = 8192 against 2.30 M), for horizons whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
+//       SIMD: the choice for larger batches (the second wave fills the first one's dependency stalls: 2.7 M solves/s
+//       at B = 8192 against 2.3 M), for horizons whose resident layout does not fit the LDS, and NMPC_QP_VARIANT=lean.
 // Same arithmetic in the same order: results are bit-identical (tests/test_gpu_parity.py).  DESIGN.md 7.
 template <class M, bool LEAN>
 struct Lds {
