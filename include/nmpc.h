@@ -35,7 +35,9 @@ extern "C" {
 /* ---- models (mathematics in DESIGN.md section 3) ----
  * Hard limits of the kernels: models 0 and 1 live in one 16x16 tile per matrix (nx, nu <= 12 in the slot layout;
  * nmpc_riccati_batch: nx <= 15, nu <= 16) and N <= 256 (four stages per lane); model 2 in 3x3 / 2x2 tiles with
- * N <= 64 (one stage per lane); rollouts N <= 128.  Violations return NMPC_E_ARG. */
+ * N <= 64 (one stage per lane); rollouts N <= 128.  Violations return NMPC_E_ARG.
+ * Environment, read by nmpc_create: NMPC_QP_VARIANT=resident|lean forces one of the two variants of the centroidal QP
+ * kernel (by default chosen per call from batch size and horizon; results are bit-identical). */
 #define NMPC_MODEL_DOUBLE_INTEGRATOR 0 /* nx 4  nu 2  np 0  ng 4  (BASELINE config 1) */
 #define NMPC_MODEL_CENTROIDAL        1 /* nx 12 nu 12 np 16 ng 16 (BASELINE config 2) */
 #define NMPC_MODEL_WHOLEBODY         2 /* nx 42 nu 30 np 20 ng 16, ny 82, ny_e 58 (BASELINE configs[2]):
