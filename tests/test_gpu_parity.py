@@ -446,6 +446,40 @@ def test_lean_variant_is_bit_identical_to_resident(dev, monkeypatch, model, N, o
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["shift", "early_exit", "nan_with_shift", "nan_without_shift"])
+def test_lean_variant_equals_resident_on_the_step_and_write_back_paths(dev, monkeypatch, case):
+    """The two variants end a solve through different code (the lean one takes a node's rows through registers: norm, step,
+    store to the caller's X, U): same trajectories, status and stats with a folded warm-start shift, with problems that
+    stop early at nlp_tol, and with a NaN problem -- which leaves the (shifted) previous solution in X, U in both."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    B, N = 7, 50
+    w = wl.centroidal_trot(B=B, N=N, seed=23)
+    if case.startswith("nan"):
+        w.x0 = w.x0.copy(); w.x0[3, 1] = np.nan
+    shift = 0 if case == "nan_without_shift" else 2
+    out = {}
+    for variant in ("resident", "lean"):
+        monkeypatch.setenv("NMPC_QP_VARIANT", variant)
+        s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=4 if case == "early_exit" else 1, nlp_tol=0.2 if case == "early_exit" else 0.0)
+        t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+        X, U, st, stats = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], shift=shift)
+        torch.cuda.synchronize()
+        out[variant] = (X.cpu().numpy(), U.cpu().numpy(), st.cpu().numpy(), stats.cpu().numpy())
+    for a, b in zip(out["resident"], out["lean"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    st = out["lean"][2]
+    if case.startswith("nan"):
+        assert st[3] == 1 and (np.delete(st, 3) == 2).all()
+        if shift == 0:                                            # untouched
+            assert np.array_equal(out["lean"][0][3], w.X[3].astype(np.float32))
+        else:                                                     # the shifted previous solution
+            assert np.array_equal(out["lean"][0][3, 1:N - shift + 1], w.X[3, 1 + shift:N + 1].astype(np.float32))
+            assert (out["lean"][1][3, N - shift:] == 0).all()
+    if case == "early_exit":
+        assert (st == 0).any() or (st == 2).all()                 # converged problems report NMPC_STATUS_OK
+
+
+@pytest.mark.gpu
 def test_batch_beyond_one_wave_per_simd_runs_in_rounds(dev, oracle32, monkeypatch):
     """B > 4 waves/CU x CUs: the library's own choice (the two-waves-per-SIMD variant beyond one problem per SIMD) equals
     the resident kernel forced onto the same batch, which runs it in rounds, bit for bit -- and both match the oracle on
