@@ -130,7 +130,8 @@ int launch_qp(Handle* h, nmpc::SolveArgs a, hipStream_t st, unsigned lin_blocks)
     for (int it = 0; it < a.max_sqp; ++it) {
         a.it = it;
         a.shift = (it == 0) ? shift : 0;     // later iterations read their own iterate
-        hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
+        if (!nmpc::qp_linearizes_itself(LEAN, a.N))
+            hipLaunchKernelGGL(nmpc::nmpc_linearize_kernel<M>, dim3(lin_blocks), dim3(64), 0, st, a);
         hipLaunchKernelGGL((nmpc::nmpc_qp_kernel<M, LEAN, BF16B, ALLV>), dim3(a.B), dim3(64), bytes, st, a);
     }
     HIP_TRY(h, hipGetLastError());

@@ -13,6 +13,12 @@
 #pragma once
 #include "nmpc_tile.hpp"
 
+// Floating-point contraction is OFF for the model functions (restored at the end of this header): they are inlined into the
+// linearisation kernel AND into the QP kernel's two-wave variant, which linearises its problem itself -- and with contraction
+// left to the backend the two instantiations fuse different products (the variants are compared bit for bit).  Unfused is also
+// what the test oracle's C code is compiled as (-ffp-contract=off).
+#pragma clang fp contract(off)
+
 namespace nmpc {
 
 struct ModelParams {
@@ -328,3 +334,5 @@ struct Centroidal {
 };
 
 }  // namespace nmpc
+
+#pragma clang fp contract(fast)

@@ -1,4 +1,5 @@
-// nmpc_solve.hip -- batched NMPC solve on gfx950: two kernels per SQP iteration.
+// nmpc_solve.hip -- batched NMPC solve on gfx950: two kernels per SQP iteration (one in the two-wave variant, which
+// linearises inside the QP kernel: qp_linearizes_itself).
 //
 // Replaces the reference's per-step solve (mpc_controller/utils/solver.py:396-403 ->
 // acados SQP / HPIPM):
@@ -223,6 +224,8 @@ struct WsLayout {
     }
 };
 constexpr int N_LANE_STAGES = 4;   // horizon limit of the lane = stage loops: N <= 256
+// true if nmpc_qp_kernel<M, LEAN, ..> linearises its problem itself (then nmpc_linearize_kernel is not launched)
+__host__ __device__ constexpr bool qp_linearizes_itself(bool lean, int N) { return lean && N < 64; }
 
 // Diagnostic build only (-DNMPC_STAMPS, tools/phase_shares.py): per-phase cycle counters written to
 // a buffer of their own; the production kernel contains no stamp.
@@ -276,18 +279,22 @@ struct Lds {
 // the LDS hand-over is ordered by issue (wave_sync), not by s_barrier -- __syncthreads would also drain
 // the column stores of the previous flush (vmcnt(0)) 25 times per thread (measured: 29.8 -> 24.8 us
 // together with requesting the reference row and the next node up front).
+// (a device function: the kernel below runs it with thread t <-> (problem, node); the two-wave variant of the QP kernel runs
+//  it itself, lane = node, in front of its prologue when the horizon fits one wave -- qp_linearizes_itself)
+constexpr int LIN_LDS_FLOATS = 64 * 16 + 2 * 64 * 2;      // column stage + the 2 x 64 tile pointers
 template <class M>
-__global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
+__device__ __forceinline__ void linearize_node(const SolveArgs& a, bool in_range, int b_in, int k_in, float* lds) {
+#pragma clang fp contract(off)      // as the model functions it calls (nmpc_models.hpp): one rounding behaviour in every caller
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NG = M::NG, NY = NX + NU;
     using G = TileGeom<M>;
-    __shared__ __attribute__((aligned(16))) float stage_col[64 * 16];
-    __shared__ float* tile_of[2][64];       // A~ / B~ tile of each thread's stage (nullptr: none)
+    float* stage_col = lds;
+    float** tile_of0 = reinterpret_cast<float**>(lds + 64 * 16);
+    float** tile_of1 = tile_of0 + 64;
+    float** tile_of[2] = {tile_of0, tile_of1};       // A~ / B~ tile of each thread's stage (nullptr: none)
     const int N = a.N;
     const int tid = threadIdx.x;
-    const long long t = (long long)blockIdx.x * blockDim.x + tid;
-    const bool in_range = t < (long long)a.B * (N + 1);
-    const int b = in_range ? (int)(t / (N + 1)) : 0;
-    const int k = in_range ? (int)(t - (long long)b * (N + 1)) : N;
+    const int b = in_range ? b_in : 0;
+    const int k = in_range ? k_in : N;
     const WsLayout<M> wl(N);
     float* ws = a.ws + (size_t)b * wl.stride;
     const bool live = in_range && !(a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]);
@@ -401,6 +408,17 @@ __global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
     M::gdot(a.mp, u, g);
 #pragma unroll
     for (int j = 0; j < NG; ++j) ws[wl.c + (size_t)k * NG + j] = g[j] - M::h(a.mp, j);
+}
+
+template <class M>
+__global__ __launch_bounds__(64) void nmpc_linearize_kernel(const SolveArgs a) {
+    __shared__ __attribute__((aligned(16))) float lin_lds[LIN_LDS_FLOATS];
+    const int N = a.N;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = t < (long long)a.B * (N + 1);
+    const int b = in_range ? (int)(t / (N + 1)) : 0;
+    const int k = in_range ? (int)(t - (long long)b * (N + 1)) : N;
+    linearize_node<M>(a, in_range, b, k, lin_lds);
 }
 
 // Element-wise pass over n floats, lane-strided, with PRE loads per lane in flight before the first
@@ -527,6 +545,18 @@ void nmpc_qp_kernel(const SolveArgs a) {
     float* Kt = ws + wl.Kt;   // transposed images of K~ (N + 1 scratch slot)
     float* Ct = ws + wl.Ct;   // transposed images of Acl~ = A~ + B~K~ (N + 1)
 
+    // Two-wave variant, horizon within one wave: the problem's linearisation runs here, lane = node, instead of in a kernel of
+    // its own (the host leaves that launch out: qp_linearizes_itself).  With a second wave on the SIMD to fill its latency this is
+    // +2 % per solve call at B = 8192; alone on the SIMD it is not (measured -0.6 % at B = 1024: the resident variant keeps the
+    // separate kernel).  Scratch: the region of the sweep operands, which the prologue below fills.
+    if constexpr (LEAN) {
+        if (qp_linearizes_itself(LEAN, N)) {
+            static_assert(LIN_LDS_FLOATS <= 4 * TS * 20, "scratch of the fused linearisation");
+            linearize_node<M>(a, lane <= N, b, lane, smem + L.qv);
+            __threadfence_block();
+            wave_sync();
+        }
+    }
     for (int i = 4 * lane; i < L.conv; i += 256)                // padding entries stay finite
         *reinterpret_cast<f32x4*>(smem + i) = zero4();
     if constexpr (LEAN)

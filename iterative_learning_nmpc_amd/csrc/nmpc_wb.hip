@@ -21,8 +21,12 @@
 // the per-stage record, the elimination columns and the transposition buffer live in the LDS (31 KB at N = 30).
 #include <hip/hip_runtime.h>
 
-#include "/root/repo/include/nmpc.h"
+#include "../../include/nmpc.h"
 #include "nmpc_wb_model.hpp"
+
+// Contraction off from here on (as in the QP kernel of nmpc_solve.hip): every intended a*b + c of this file is an fmaf or an MFMA;
+// what the backend would fuse on its own depends on the instantiation.
+#pragma clang fp contract(off)
 
 namespace nmpc {
 namespace wb {

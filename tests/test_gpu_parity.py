@@ -163,8 +163,8 @@ def test_centroidal_solve_parity(dev, oracle64, oracle32, n_ipm, sqp):
     print(f"n_ipm={n_ipm} sqp={sqp}: gpu-vs-f64 X {eX:.2e} U {eU:.2e}; gpu-vs-f32 X {rel(X, X32):.2e} "
           f"U {rel(U, U32):.2e}; f32-vs-f64 floor {floor:.2e}")
     assert np.array_equal(st, st64)
-    # measured gpu-vs-fp64 (X / U): 4.4e-6 / 9e-7, 4.2e-6 / 1.0e-6, 8.8e-6 / 1.1e-6 (fp32 oracle itself 7.8e-6), 9.7e-7 / 2.2e-7,
-    # 1.1e-6 / 2.4e-7: fifteen iterations contract the rounding differences, they do not amplify them
+    # measured gpu-vs-fp64 (X / U): 4.2e-6 / 9e-7, 4.1e-6 / 1.0e-6, 9.6e-6 / 1.2e-6 (fp32 oracle itself 7.8e-6), 9.7e-7 / 2.2e-7,
+    # 1.0e-6 / 2.3e-7: fifteen iterations contract the rounding differences, they do not amplify them
     assert _within_tolerance(eX, rel(X32, X64)) and eU < 1e-5, (eX, eU, floor)
     assert rel(X, X32) < 1e-5 and rel(U, U32) < 1e-5                 # and against the fp32 oracle (measured <= 6.2e-6)
     assert np.allclose(stats[:, 0], stats64[:, 0], rtol=1e-4)       # cost at linearisation
@@ -186,7 +186,7 @@ def test_centroidal_active_friction(dev, oracle64, oracle32):
     viol = np.maximum(np.abs(f[..., :2]).max(-1) - 0.3 * f[..., 2], 0) * c
     assert viol.max() < 1e-3
     X32, U32, _, _ = _oracle_solve(oracle32, w, n_ipm=6)
-    # measured 1.65e-5 / 5.3e-6 with the fp32 oracle itself at 1.65e-5 / 4.6e-6: the stiff barrier system, not the kernel
+    # measured 1.84e-5 / 4.6e-6 with the fp32 oracle itself at 1.65e-5 / 4.6e-6: the stiff barrier system, not the kernel
     assert _within_tolerance(rel(X, X64), rel(X32, X64)) and rel(U, U64) < 1e-5, (rel(X, X64), rel(U, U64), rel(X32, X64))
 
 
