@@ -293,7 +293,7 @@ __device__ __forceinline__ void linearize_node(const SolveArgs& a, bool in_range
     float** tile_of[2] = {tile_of0, tile_of1};       // A~ / B~ tile of each thread's stage (nullptr: none)
     const int N = a.N;
     const int tid = threadIdx.x;
-    const int b = in_range ? b_in : 0;
+    const int b = b_in;                   // a valid problem index also where in_range is false (idle lanes only read it)
     const int k = in_range ? k_in : N;
     const WsLayout<M> wl(N);
     float* ws = a.ws + (size_t)b * wl.stride;
