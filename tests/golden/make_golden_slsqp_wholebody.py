@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cross-check of the oracle's whole-body model (model 2) by an independent NLP solver at a horizon of N nodes (default 10).
 
-    python tests/golden/make_golden_slsqp_wholebody.py [N]      # N = 10: 5.5 minutes, 499 iterations; writes slsqp_wholebody_n<N>.npz
+    python tests/golden/make_golden_slsqp_wholebody.py [N]      # N = 10: 5.5 minutes, 499 iterations; N = 20: 2.5 hours, 566 iterations; writes slsqp_wholebody_n<N>.npz
 
 scipy's SLSQP on the NLP of one seeded whole-body problem (low friction: pyramid faces active; commanded forward speed),
 with analytic gradients: the cost gradient from the oracle's residual Jacobian, the constraint Jacobian from its A, B
