@@ -88,8 +88,13 @@ typedef struct {
                    /*     -- whole-body: Q~ = Js'Js of the dense residual Jacobian;    */
                    /*     centroidal: the barrier product G'DG | G'v (the only dense   */
                    /*     contraction that model has) --, everything else fp32;        */
-                   /* 2 = whole-body only: split bf16, Js = hi + lo, three products.   */
-                   /* Measured deviations: DESIGN.md 7 (1: ~1e-3, 2: ~1e-5 level).     */
+                   /* 2 = whole-body only: split bf16, Js = hi + lo, three products;   */
+                   /* 3 = whole-body only: three-way split, Js = hi + mid + lo (the 24  */
+                   /*     bits of the fp32 Jacobian), six bf16 products, fp32 accumu-   */
+                   /*     lation: the recommended configs[4] variant, inside the 1e-5   */
+                   /*     bar at the steady-state policy.                               */
+                   /* Measured deviations: DESIGN.md 7 (1: ~3e-3, 2: ~1e-4, 3: ~7e-6   */
+                   /* after one SQP iteration).                                         */
 } nmpc_dims;
 
 /* Dimensions of a model.  Any out pointer may be NULL. */
@@ -198,6 +203,16 @@ typedef struct {
     float stance_ratio[4];             /* gait configuration (mpc_gait.py:15-21)                          */
     float nominal_period;
     float foot_size;                   /* z of a planned location (mpc.py:89: 0.0085)                     */
+    /* Early termination (the reference's simulator ends a rollout whose robot falls or whose controller diverges, and the
+     * data collection discards it and rolls again: DAgger/utils/RolloutMPC.py:424-437,
+     * DAgger/example/data_collection_pretrain_omini_vc_policy_1direction_perturbed.py:217-247).  A rollout that raises
+     * one of the bits of terminate_mask is frozen from the next replan on: its plant, feet and trajectories stay, its
+     * solves are skipped, its remaining rows of S repeat the last recorded one, and failed[b] records the replan that
+     * terminated it.  0: nothing terminates (flags are still raised). */
+    int terminate_mask;
+    float collision_height;            /* base height [m] below which NMPC_ROLLOUT_FLAG_COLLISION is raised [decl: 0.08,
+                                        * the trunk on the ground -- the simulator of the reference allows only the feet
+                                        * to touch the floor, RolloutMPC.py:404] */
 } nmpc_rollout_cfg;
 /* bits of failed[b] (sticky over the rollout): the solver's NaN / QP failure, and the reference's unsafe-state
  * predicates on the recorded states (check_unsafe_state_v2, DAgger/utils/Rollout_combined_controller.py:367-431;
@@ -207,6 +222,9 @@ typedef struct {
 #define NMPC_ROLLOUT_FLAG_PITCH         4   /* |pitch| > 25 deg                     */
 #define NMPC_ROLLOUT_FLAG_HEIGHT        8   /* base height outside [0.18, 0.45] m   */
 #define NMPC_ROLLOUT_FLAG_VEL_TRACKING 16   /* |v_xy - v_des_xy| > 0.10 m/s         */
+#define NMPC_ROLLOUT_FLAG_COLLISION    32   /* base height < cfg.collision_height: the robot lies on the ground [decl] */
+#define NMPC_ROLLOUT_FLAG_MASK       0xFF   /* the flag bits of failed[b] ...                                          */
+#define NMPC_ROLLOUT_TERM_SHIFT         8   /* ... and above them 1 + the index of the replan that terminated the rollout (0: ran to the end) */
 /* gait: dev int8 [4][nodes_per_cycle]; x: dev [B][12] in initial / out final state; v_des, w_des: dev
  * double [B][3] (commands are kept in fp64 like the reference's, so the integrated reference matches); ref_state: dev double [B][12] in/out (the controller's integrated base reference);
  * foot_pos: dev [B][4][3] in/out (out only with cfg.footsteps); push_force: dev [B][3] or NULL; phase: host
@@ -220,6 +238,12 @@ int nmpc_rollout_batch(void *handle, int B, const nmpc_rollout_cfg *cfg, const s
                        const double *v_des, const double *w_des, double *ref_state, float *foot_pos,
                        const float *push_force, const float *phase, float *X, float *U, float *S,
                        int *status, int *failed, void *stream);
+
+/* Problems to leave out of the following *_batch solves of this handle: flags dev int[B_max] (or NULL: none); a problem
+ * with flags[b] & mask != 0 is skipped by every kernel -- its X, U, status, stats stay as they are and it costs no
+ * time.  The flags are read when the kernels run (stream order), so the caller may update them between calls without
+ * calling this again.  nmpc_rollout_batch uses its own failed[] / terminate_mask for the duration of the call. */
+int nmpc_set_skip(void *handle, const int *flags, int mask);
 
 /* Test hook: copy one stage tile of problem b out of the workspace after a solve.
  * which: 0 = A~ = [A d; 0 1], 1 = B~, 2 = K~ = [K kff], 3 = A~ + B~K~ (last sweep).

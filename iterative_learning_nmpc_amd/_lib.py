@@ -25,6 +25,7 @@ SIGNATURES = {
     "nmpc_set_weights": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), c_float, c_float]),
     "nmpc_set_opts": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_int]),
     "nmpc_set_contact_patterns": (c_int, [c_void_p, c_int]),
+    "nmpc_set_skip": (c_int, [c_void_p, c_void_p, c_int]),
     "nmpc_set_ipm": (c_int, [c_void_p, c_float, c_float, c_float, c_float, c_float, c_float]),
     "nmpc_shift_warm_start": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nmpc_solve_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
@@ -89,7 +90,8 @@ class NmpcRolloutCfg(ctypes.Structure):
                 ("sim_dt", ctypes.c_double), ("time_horizon", ctypes.c_double), ("nom_height", ctypes.c_double),
                 ("height_offset", ctypes.c_double), ("push_start", c_float), ("push_duration", c_float),
                 ("footsteps", c_int), ("record_sim_steps", c_int), ("hip_offset", c_float * 8),
-                ("stance_ratio", c_float * 4), ("nominal_period", c_float), ("foot_size", c_float)]
+                ("stance_ratio", c_float * 4), ("nominal_period", c_float), ("foot_size", c_float),
+                ("terminate_mask", c_int), ("collision_height", c_float)]
 
 
 class NmpcDims(ctypes.Structure):

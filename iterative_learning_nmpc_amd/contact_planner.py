@@ -145,7 +145,9 @@ class RaiberContactPlanner(ContactPlanner):
             ratio = self.config_gait.stance_ratio[foot]
             t_stance = self.config_gait.nominal_period * ratio
             hip = com_xy + (R_yaw @ self.offset_hip_b[foot])[:2] + v_cmd * t_touch * (1 + ratio)
-            lever = 0.5 * np.sqrt(com_z / self.GRAVITY) * v_cmd
+            # (max: the reference's sqrt(com_z / g), contact_planner.py:311, is NaN for a base below the ground -- a state its
+            #  simulator cannot reach, the centroidal plant can)
+            lever = 0.5 * np.sqrt(max(com_z, 0.0) / self.GRAVITY) * v_cmd
             centrifugal = np.array([lever[1] * self.w_yaw, -lever[0] * self.w_yaw])  # (lever,0) x (0,0,w)
             target = np.zeros(3)
             target[:2] = hip + 0.1 * (v_cmd - self.v_w[:2]) + 0.5 * v_cmd * t_stance + centrifugal[:2]

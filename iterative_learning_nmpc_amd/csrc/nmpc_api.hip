@@ -31,10 +31,13 @@ struct Handle {
     int n_cu = 256;          // compute units of the device
     int force_variant = 0;   // NMPC_QP_VARIANT: 0 chosen per call by batch size and horizon (launch_solve), 1 resident, 2 lean (tests, tuning)
     int all_patterns = 0;    // nmpc_set_contact_patterns: 1 = kernel with a static stage body per contact pattern
+    const int* skip = nullptr;   // nmpc_set_skip: problems with skip[b] & skip_mask != 0 are left out of the solves
+    int skip_mask = 0;
     bool ws_dirty = false;   // a dense-LQ call left foreign padding in the tile workspace
     bool mp_set = false, w_set = false;
     nmpc::ModelParams mp{};
-    float W[96]{}, We[64]{};
+    float W[96]{}, We[96]{};
+    bool pos_rows = false;   // whole-body: some foot-placement weight is non-zero
     float reg = 1e-6f, reg_e = 1e-5f;
     int max_sqp = 1, n_ipm = 6, line_search = 0;
     float nlp_tol = 0.0f, qp_tol = 1e-2f;
@@ -69,6 +72,7 @@ nmpc::SolveArgs base_args(const Handle* h) {
     a.gamma = h->gamma; a.tau_min = h->tau_min; a.rho = h->rho;
     a.ws = h->ws;
     a.dbg = h->dbg;
+    a.skip = h->skip_mask ? h->skip : nullptr; a.skip_mask = h->skip_mask;
     return a;
 }
 
@@ -85,9 +89,11 @@ nmpc::wb::WbArgs wb_args(const Handle* h) {
     a.N = h->dims.N;
     a.max_sqp = h->max_sqp; a.n_ipm = h->n_ipm;
     a.precision = h->dims.precision;
+    a.pos_rows = h->pos_rows ? 1 : 0;
     a.nlp_tol = h->nlp_tol; a.mu0 = h->mu0; a.sigma = h->sigma; a.s_min = h->s_min;
     a.gamma = h->gamma; a.tau_min = h->tau_min;
     a.ws = h->ws;
+    a.skip = h->skip_mask ? h->skip : nullptr; a.skip_mask = h->skip_mask;
     return a;
 }
 
@@ -233,8 +239,8 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     int nx, nu, np, ng;
     if (nmpc_model_dims(dims->model_id, &nx, &nu, &np, &ng)) return fail(nullptr, NMPC_E_ARG, "unknown model_id");
     if (dims->N < 1 || dims->B_max < 1) return fail(nullptr, NMPC_E_ARG, "N and B_max must be positive");
-    if (dims->precision < 0 || dims->precision > 2 || (dims->precision == 2 && dims->model_id != NMPC_MODEL_WHOLEBODY))
-        return fail(nullptr, NMPC_E_ARG, "precision must be 0 (fp32), 1 (bf16 contraction) or, whole-body only, 2 (split bf16)");
+    if (dims->precision < 0 || dims->precision > 3 || (dims->precision >= 2 && dims->model_id != NMPC_MODEL_WHOLEBODY))
+        return fail(nullptr, NMPC_E_ARG, "precision must be 0 (fp32), 1 (bf16 contraction) or, whole-body only, 2 (split bf16) / 3 (three-way split bf16)");
     Handle* h = new Handle();
     h->dims = *dims;
     h->device = device_id;
@@ -321,6 +327,12 @@ int nmpc_set_weights(void* handle, const float* W, const float* W_e, float reg, 
     if (!(reg >= 0.0f) || !(reg_e >= 0.0f)) return fail(h, NMPC_E_ARG, "regularisation must be non-negative");
     h->reg = reg; h->reg_e = reg_e;
     h->w_set = true;
+    if (h->dims.model_id == NMPC_MODEL_WHOLEBODY) {
+        bool pos = false;
+        for (int i = 0; i < 8; ++i) pos = pos || W[nmpc::wb::RY_POS + i] > 0.0f || W_e[nmpc::wb::RE_POS + i] > 0.0f;
+        if (h->pos_rows && !pos) h->ws_dirty = true;     // the foot-placement rows of the Js images go back to exact zeros
+        h->pos_rows = pos;
+    }
     return NMPC_OK;
 }
 
@@ -338,6 +350,14 @@ int nmpc_set_contact_patterns(void* handle, int all_patterns) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return NMPC_E_ARG;
     h->all_patterns = all_patterns ? 1 : 0;
+    return NMPC_OK;
+}
+
+int nmpc_set_skip(void* handle, const int* flags, int mask) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    h->skip = flags;
+    h->skip_mask = flags ? mask : 0;
     return NMPC_OK;
 }
 
@@ -366,7 +386,7 @@ int nmpc_shift_warm_start(void* handle, int B, int shift, float* X, float* U, vo
     nmpc::DeviceGuard guard(h->device);
     HIP_TRY(h, guard.err);
     hipLaunchKernelGGL(nmpc::nmpc_shift_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       N, h->nx, h->nu, shift, X, U);
+                       N, h->nx, h->nu, h->dims.model_id == NMPC_MODEL_WHOLEBODY ? nmpc::wb::WF : 0, shift, X, U);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
 }
@@ -494,6 +514,7 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
     r.push_force = push_force; r.yref = yref; r.yref_e = yref_e; r.params = params;
     r.X = X; r.U = U; r.S = S; r.status = status; r.failed = failed;
     r.footsteps = cfg->footsteps ? 1 : 0; r.record_sim_steps = cfg->record_sim_steps ? 1 : 0;
+    r.term_mask = cfg->terminate_mask & NMPC_ROLLOUT_FLAG_MASK; r.collision_height = cfg->collision_height;
     std::memcpy(r.hip_offset, cfg->hip_offset, sizeof(r.hip_offset));
     std::memcpy(r.stance_ratio, cfg->stance_ratio, sizeof(r.stance_ratio));
     r.nominal_period = cfg->nominal_period; r.foot_size = cfg->foot_size;
@@ -504,6 +525,7 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
     a.B = B; a.yref_per_stage = 1;
     a.x0 = x; a.yref = yref; a.yref_e = yref_e; a.params = params; a.X = X; a.U = U;
     a.status = status; a.stats = nullptr;
+    a.skip = r.term_mask ? failed : nullptr; a.skip_mask = r.term_mask;     // terminated rollouts cost no solve
     const float dt_replan = (float)(cfg->replanning_steps * cfg->sim_dt);
     for (int i = 0; i < cfg->n_replans; ++i) {
         const bool cold = cfg->first_solve && i == 0;
@@ -512,9 +534,11 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         r.replan_index = i;
         r.row0 = i * rows_per_replan;
         r.phase = phase[i];
-        const float t_now = i * dt_replan;
-        r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= cfg->push_start &&
-                     t_now < cfg->push_start + cfg->push_duration) ? dt_replan : 0.0f;
+        // the push window in replanning intervals, half a simulation step of slack on both ends: with plain float compares
+        // 5 * 0.04f = 0.19999999 misses a window that starts at 0.2 (the host loop, in doubles, does not)
+        const double t_now = i * (cfg->replanning_steps * cfg->sim_dt), slack = 0.5 * cfg->sim_dt;
+        r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= (double)cfg->push_start - slack &&
+                     t_now < (double)cfg->push_start + (double)cfg->push_duration - slack) ? dt_replan : 0.0f;
         hipLaunchKernelGGL(nmpc::nmpc_rollout_prepare_kernel, dim3(B), dim3(64), 0, st, r);
         a.shift = cold ? 0 : (cfg->nodes_per_replan > N ? N : cfg->nodes_per_replan);   // warm start folded into the solve
         a.max_sqp = cold ? cfg->max_sqp_first : h->max_sqp;

@@ -50,7 +50,11 @@ struct SolveArgs {
     float* stats;
     float* ws;            // workspace, WsLayout per problem
     float* dbg;           // diagnostic builds: [B][8] phase cycle counts, else unused
+    const int* skip;      // nullptr, or dev [B] flag words: a problem with skip[b] & skip_mask != 0 is left untouched
+    int skip_mask;        // (terminated rollouts, nmpc_set_skip)
 };
+
+__device__ __forceinline__ bool skipped(const SolveArgs& a, int b) { return a.skip && (a.skip[b] & a.skip_mask) != 0; }
 
 __host__ __device__ inline int round4(int n) { return (n + 3) & ~3; }
 
@@ -297,7 +301,7 @@ __device__ __forceinline__ void linearize_node(const SolveArgs& a, bool in_range
     const int k = in_range ? k_in : N;
     const WsLayout<M> wl(N);
     float* ws = a.ws + (size_t)b * wl.stride;
-    const bool live = in_range && !(a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]);
+    const bool live = in_range && !(a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]) && !skipped(a, b);
     const bool stage = live && k < N;       // this thread linearises a shooting interval
     const int ks = stage ? k : 0;
     const float* Xg = a.X + (size_t)b * (N + 1) * NX;
@@ -472,6 +476,7 @@ void nmpc_qp_kernel(const SolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
+    if (skipped(a, b)) return;                   // e.g. a terminated rollout: X, U, status stay as they are
     const int lane = lane_id();
     const int q4 = lane >> 4, c = lane & 15;
     const int N = a.N;

@@ -55,7 +55,8 @@ struct WbArgs {
     float reg, reg_e;
     int N, B;
     int max_sqp, n_ipm, yref_per_stage, it, shift;
-    int precision;      // 0: fp32; 1: bf16 residual Jacobian, J'WJ on the bf16 matrix pipe; 2: split bf16 (hi + lo)
+    int precision;      // 0: fp32; 1: bf16 residual Jacobian, J'WJ on the bf16 matrix pipe; 2: split bf16 (hi + lo); 3: hi + mid + lo
+    int pos_rows;       // 1: some foot-placement weight (W / W_e rows RY_POS.., RE_POS..) is non-zero
     float nlp_tol, mu0, sigma, s_min, gamma, tau_min;
     const float* x0;
     const float* yref;
@@ -66,6 +67,8 @@ struct WbArgs {
     int* status;
     float* stats;
     float* ws;
+    const int* skip;    // nullptr, or dev [B] flag words: a problem with skip[b] & skip_mask != 0 is left untouched (nmpc_set_skip)
+    int skip_mask;
 };
 
 __host__ __device__ inline int r4(int n) { return (n + 3) & ~3; }
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
     const WsLayout wl(N);
     float* ws = a.ws + (size_t)b * wl.stride;
     if (a.it > 0 && reinterpret_cast<const int*>(ws + wl.flag)[0]) return;
+    if (a.skip && (a.skip[b] & a.skip_mask) != 0) return;
     const bool term = (k == N);
     const ModelParams& mp = a.mp;
     const float dt = mp.dt;
@@ -138,10 +142,12 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
     for (int i = 0; i < NX; ++i) x[i] = xk[i];
     const int ks = term ? 0 : k;
     {
+        // warm-start shift as an index map; in the exposed tail the contact forces are zero and the accelerations keep the
+        // previous solution's values at that stage (solver.py:316-322 moves a[:, :n_warm_start] and zeroes f[:, n_warm_start:])
         const bool ok = (a.shift == 0) || shifted_stage_valid(ks, a.shift, N);
         const float* uk = Ug + (size_t)(ok ? ks + a.shift : ks) * NU;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = ok ? uk[i] : 0.0f;
+        for (int i = 0; i < NU; ++i) u[i] = (ok || i < WF) ? uk[i] : 0.0f;
     }
     const float* pg = a.params + ((size_t)b * (N + 1) + k) * NP;
 #pragma unroll
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                            : a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) + (a.yref_per_stage ? (size_t)k * NY : 0);
     const float* Wv = term ? a.We : a.W;
     const int r_sw = term ? RE_SWING : RY_SWING, r_ct = term ? RE_CNT : RY_CNT, r_cs = term ? RE_CONS : RY_CONS;
+    const int r_ps = term ? RE_POS : RY_POS;
     (void)ny;
 
     // ---- kinematics
@@ -206,6 +213,21 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
             for (int i = 0; i < 3; ++i) { J[i][6 + c] = t0[i]; Jd[i][6 + c] = t1[i] + t2[i]; }
         }
         const float cf = p[f], peak = p[4 + f], ppz = p[8 + 3 * f + 2];
+        // foot-placement rows (pos_cost, solver.py:128-137,272-273): world x, y of the foot - planned location.  Weight 0
+        // outside the contact-restricted mode: the rows are then exact zeros in the image and are not rewritten
+        // (a.pos_rows, wave-uniform; nmpc_set_weights has the image cleared when the rows go from weighted to unweighted)
+        if (a.pos_rows) {
+            const float px[2] = {x[WQ] + Rb[0], x[WQ + 1] + Rb[1]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float w = Wv[r_ps + 2 * f + i], sw = sqrtf(w);
+                const float res = px[i] - yr[r_ps + 2 * f + i];
+                cost += 0.5f * w * res * res;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) put_js(22 + 2 * f + i, WQ + xi_col(f, c), sw * J[i][c]);
+                put_js(22 + 2 * f + i, HX, sw * res);
+            }
+        }
         // swing row: peak z_foot - ref
         {
             const float w = Wv[r_sw + f], sw = sqrtf(w);
@@ -470,6 +492,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b >= a.B) return;
+    if (a.skip && (a.skip[b] & a.skip_mask) != 0) return;
     const int lane = lane_id();
     const int q4 = lane >> 4, c = lane & 15;
     const int N = a.N;
@@ -531,17 +554,22 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // bf16 tail, J = hi + lo -- and contracted on the bf16 matrix pipe with fp32 accumulation
         // (v_mfma_f32_16x16x16_bf16: one instruction per 16 residual rows where fp32 takes four steps); the accumulator
         // layout of a tile is that instruction's operand layout (nmpc_tile.hpp).  Everything downstream stays fp32.
-        s16x4 Jh[JT][XT], Jl[JT][XT];
+        s16x4 Jh[JT][XT], Jm[JT][XT], Jl[JT][XT];
         if (a.precision != 0) {
+            auto widen = [](s16x4 v) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = __uint_as_float(((unsigned)(unsigned short)v[r]) << 16);
+                return o;
+            };
 #pragma unroll
             for (int t = 0; t < JT; ++t)
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
                     Jh[t][j] = to_bf16x4(J[t][j]);
-                    f32x4 back;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) back[r] = __uint_as_float(((unsigned)(unsigned short)Jh[t][j][r]) << 16);
-                    Jl[t][j] = to_bf16x4(J[t][j] - back);
+                    const f32x4 r1 = J[t][j] - widen(Jh[t][j]);          // exact: the head's 8 bits leave a 16-bit remainder
+                    Jm[t][j] = to_bf16x4(r1);                            // precision 2 calls this part "lo"
+                    Jl[t][j] = to_bf16x4(r1 - widen(Jm[t][j]));          // precision 3 only: J = hi + mid + lo to 24 bits
                 }
         }
         // diagonal, gradient column / row, and store -- called right behind the products of each precision branch, so
@@ -569,7 +597,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     for (int t = 0; t < JT; ++t) acc = xty(J[t][i], J[t][j], acc);
                     finish(i, j, acc);
                 }
-        } else {
+        } else if (a.precision != 3) {
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
@@ -579,10 +607,36 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     for (int t = 0; t < JT; ++t) {
                         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jh[t][j], acc, 0, 0, 0);
                         if (a.precision == 2) {      // (hi + lo)'(hi + lo) without the lo'lo term (2^-16 of the product)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jl[t][j], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jl[t][i], Jh[t][j], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jm[t][j], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jm[t][i], Jh[t][j], acc, 0, 0, 0);
                         }
                     }
+                    finish(i, j, acc);
+                }
+        } else {
+            // three-way split: J = hi + mid + lo carries the 24 bits of the fp32 Jacobian; of the nine products the six of
+            // relative size >= 2^-16 are formed (mid'lo, lo'mid, lo'lo are below fp32 rounding), smallest first, each
+            // bf16 x bf16 product exact in the fp32 accumulator: the Hessian differs from the fp32 contraction by
+            // accumulation order only.  Six instructions of K = 16 per 16 residual rows against four fp32 steps of K = 4.
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int j = 0; j < XT; ++j) {
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int t = 0; t < JT; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jl[t][i], Jh[t][j], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jl[t][j], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jm[t][i], Jm[t][j], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < JT; ++t) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jm[t][i], Jh[t][j], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jm[t][j], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < JT; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Jh[t][i], Jh[t][j], acc, 0, 0, 0);
                     finish(i, j, acc);
                 }
         }
@@ -592,7 +646,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     float cost_l = 0.0f, mu_l = 0.0f;
     int nact_l = 0;
     unsigned my_act = 0u;
-    if (lane <= N) cost_l = recs[(size_t)lane * REC + R_COST];
+    for (int k = lane; k <= N; k += 64) cost_l += recs[(size_t)k * REC + R_COST];     // (N = 64: node 64 has no lane of its own)
     if (lane < N) {
         const float* rec = recs + (size_t)lane * REC;
         my_act = reinterpret_cast<const unsigned*>(rec)[R_ACT];
@@ -1191,7 +1245,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 const int k = ec / NU, i = ec - k * NU;
                 const bool okk = a.shift == 0 || shifted_stage_valid(k, a.shift, N);
                 const float t = Ug[ec + (okk ? a.shift * NU : 0)];
-                v[uu] = (okk ? t : 0.0f) + (bad ? 0.0f : sc * AT(dU, k, i));
+                v[uu] = ((okk || i < WF) ? t : 0.0f) + (bad ? 0.0f : sc * AT(dU, k, i));
             }
             if (a.shift > 0) phase_sync();
 #pragma unroll

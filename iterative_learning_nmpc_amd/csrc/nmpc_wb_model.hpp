@@ -8,8 +8,10 @@
 // by the test oracle as its model 2) is evaluated here lane-locally, one thread per (problem, node):
 //   semi-implicit Euler  v+ = v + dt a, q+ = q + dt v+, h_lin+ = h_lin + dt (sum c_i f_i + m g),
 //   h_ang+ = h_ang + dt sum c_i (p_i(q) - r) x f_i ; legs = hip abduction (x), thigh (y), knee (y), point foot.
-// Residuals of the Gauss-Newton cost (order of W / yref, ny = 82; terminal ny_e = 58 without acc, f_reg):
-//   base(12) joint(24) acc(12) swing(4) f_reg(12) contact(12) consist(6)
+// Residuals of the Gauss-Newton cost (order of W / yref, ny = 90; terminal ny_e = 66 without acc, f_reg):
+//   base(12) joint(24) acc(12) swing(4) f_reg(12) contact(12) consist(6) pos(8)
+// pos = world (x, y) of each foot against the planned location: the reference's pos_cost, weighted by W_foot_displacement in
+// its contact-restricted mode and by 0 otherwise (solver.py:128-137,272-273)
 // (dynamics.py:121-134, solver.py:108-141,170-177; contact = Baumgarte-stabilised stance constraint with
 //  p_gain = W_foot_pos_constr_stab, consist = h - A_g(q) v, both as quadratic penalties).
 #pragma once
@@ -18,11 +20,11 @@
 namespace nmpc {
 namespace wb {
 
-constexpr int NX = 42, NU = 30, NP = 20, NG = 16, NY = 82, NYE = 58;
+constexpr int NX = 42, NU = 30, NP = 20, NG = 16, NY = 90, NYE = 66;
 constexpr int WQ = 0, WV = 18, WH = 36, WA = 0, WF = 18;
-constexpr int RY_BASE = 0, RY_JOINT = 12, RY_ACC = 36, RY_SWING = 48, RY_FREG = 52, RY_CNT = 64, RY_CONS = 76;
-constexpr int RE_BASE = 0, RE_JOINT = 12, RE_SWING = 36, RE_CNT = 40, RE_CONS = 52;
-constexpr int NJR = 22;    // dense residual rows: contact 12 (rows 0..11), swing 4 (12..15), consist 6 (16..21)
+constexpr int RY_BASE = 0, RY_JOINT = 12, RY_ACC = 36, RY_SWING = 48, RY_FREG = 52, RY_CNT = 64, RY_CONS = 76, RY_POS = 82;
+constexpr int RE_BASE = 0, RE_JOINT = 12, RE_SWING = 36, RE_CNT = 40, RE_CONS = 52, RE_POS = 58;
+constexpr int NJR = 30;    // dense residual rows: contact 12 (rows 0..11), swing 4 (12..15), consist 6 (16..21), foot placement 8 (22..29)
 
 struct M3 { float m[9]; };
 __device__ __forceinline__ M3 mul(const M3& a, const M3& b) {

@@ -31,6 +31,43 @@ from .workloads import FEET, HIP_OFFSETS, MODEL_CENTROIDAL, model_params
 
 N_SQP_FIRST = 15   # mpc.py:465
 
+# bits of `failed` (include/nmpc.h NMPC_ROLLOUT_FLAG_*); above them 1 + the replan that terminated the rollout
+FLAG_SOLVER, FLAG_ROLL, FLAG_PITCH, FLAG_HEIGHT, FLAG_VEL_TRACKING, FLAG_COLLISION = 1, 2, 4, 8, 16, 32
+FLAG_MASK, TERM_SHIFT = 0xFF, 8
+# what ends a rollout early and makes the data collection discard and redo it: the controller diverged or the robot lies
+# on the ground (the reference: mpc.diverged / a collision the simulator does not allow, RolloutMPC.py:404,424-437)
+TERMINATE_DEFAULT = FLAG_SOLVER | FLAG_COLLISION
+COLLISION_HEIGHT = 0.08      # [decl] base height of a trunk that touches the floor
+
+
+def sample_pushes(n: int, seed, start: float = 0.0, duration: float = 0.3, magnitude=(50.0, 70.0)) -> dict:
+    """n base pushes as the reference's data collection draws them (bc_experimental.yaml:32-35,
+    data_collection_force_perturbation.py:213-248): direction uniform in the cube, normalised, magnitude uniform in
+    `magnitude` newtons.  seed: anything numpy's SeedSequence takes (e.g. (rank, iteration, attempt))."""
+    rng = np.random.default_rng(seed)
+    force = rng.uniform(-1.0, 1.0, (n, 3))
+    force /= np.linalg.norm(force, axis=1, keepdims=True) + 1e-6
+    force *= rng.uniform(magnitude[0], magnitude[1], (n, 1))
+    return dict(start=float(start), duration=float(duration), force=force)
+
+
+def state_row_flags(rows: np.ndarray, v_des: np.ndarray, collision_height: float = COLLISION_HEIGHT) -> np.ndarray:
+    """NMPC_ROLLOUT_FLAG_* bits of recorded 19-slot state rows [B, R, 19] (check_unsafe_state_v2,
+    Rollout_combined_controller.py:367-431, + the collision height), OR-ed over the R rows: what the device's advance
+    kernel raises, in fp32 like it."""
+    r = np.asarray(rows, np.float32)
+    lim = np.float32(25.0) * np.float32(0.017453292519943295)
+    vd = np.asarray(v_des, np.float64).astype(np.float32)
+    f = np.zeros(r.shape[:2], np.int32)
+    f |= np.where(np.abs(r[:, :, 10]) > lim, FLAG_ROLL, 0)
+    f |= np.where(np.abs(r[:, :, 9]) > lim, FLAG_PITCH, 0)
+    f |= np.where((r[:, :, 7] < np.float32(0.18)) | (r[:, :, 7] > np.float32(0.45)), FLAG_HEIGHT, 0)
+    f |= np.where((np.abs(r[:, :, 1] - vd[:, None, 0]) > np.float32(0.10)) | (np.abs(r[:, :, 2] - vd[:, None, 1]) > np.float32(0.10)),
+                  FLAG_VEL_TRACKING, 0)
+    f |= np.where(r[:, :, 7] < np.float32(collision_height), FLAG_COLLISION, 0)
+    f |= np.where(~(np.abs(r[:, :, 7]) <= np.float32(1e30)), FLAG_SOLVER, 0)
+    return np.bitwise_or.reduce(f, axis=1)
+
 
 def base_ref_vel_tracking_batch(q, v_des, w_des, ref_state, t_horizon, nom_height, height_offset=0.0):
     """Vectorised `compute_base_ref_vel_tracking` (mpc.py:210-272) for q[B,>=4], v_des[B,3],
@@ -69,12 +106,17 @@ class BatchedLocomotionMPC:
     def __init__(self, batch: int, gait_name: str = "trot", robot_name: str = "go2", n_nodes: int = 50,
                  device="cuda:0", sim_dt: float = 1.0e-3, height_offset: float = 0.0,
                  compute_timings: bool = True, mass: float = 15.0, inertia=(0.11, 0.27, 0.33),
-                 footsteps: bool = False, record_sim_steps: bool = False):
+                 footsteps: bool = False, record_sim_steps: bool = False, terminate_mask: int = TERMINATE_DEFAULT,
+                 collision_height: float = COLLISION_HEIGHT):
         """footsteps: stance feet anchored, touch-downs at Raibert targets (False: the feet stay under the initial hips
         for the whole rollout -- the stance-frozen rollouts of round 1).  record_sim_steps: one state row per
         simulation step (the plan up-sampled as mpc.py:371-414) instead of one per replan."""
         self.batch = int(batch)
         self.footsteps, self.record_sim_steps = bool(footsteps), bool(record_sim_steps)
+        # early termination (include/nmpc.h, nmpc_rollout_cfg.terminate_mask): a rollout that raises one of these flags is
+        # frozen; `invalid_mask` is what open_loop_device_valid discards and redoes (the same bits by default)
+        self.terminate_mask, self.collision_height = int(terminate_mask) & FLAG_MASK, float(collision_height)
+        self.invalid_mask = self.terminate_mask
         self.config_gait, self.config_opt, self.config_cost = get_quadruped_config(gait_name, robot_name)
         self.n_nodes = int(n_nodes)
         self.height_offset = height_offset
@@ -139,8 +181,13 @@ class BatchedLocomotionMPC:
                                            self.config_opt.time_horizon, self.config_gait.nom_height,
                                            self.height_offset)
 
-    def increment_base_ref_position(self, n_steps: int = 1) -> None:
-        """mpc.py:204-208, once per simulation step, vectorised over the batch."""
+    def increment_base_ref_position(self, n_steps: int = 1, rows=None) -> None:
+        """mpc.py:204-208, once per simulation step, vectorised over the batch (rows: mask of the rollouts that advance)."""
+        if rows is not None and not rows.all():
+            keep = self.base_ref_vel_tracking[~rows].copy()
+            self.increment_base_ref_position(n_steps)
+            self.base_ref_vel_tracking[~rows] = keep
+            return
         s = self.base_ref_vel_tracking
         for _ in range(n_steps):
             cr, sr = np.cos(s[:, 5]), np.sin(s[:, 5])
@@ -187,11 +234,14 @@ class BatchedLocomotionMPC:
             out[b] = np.moveaxis(locs, 0, 1)
         return out
 
-    def touch_down(self, params: np.ndarray) -> None:
-        """feet that stand at the node the plant has reached are where the plan put them"""
+    def touch_down(self, params: np.ndarray, rows=None) -> None:
+        """feet that stand at the node the plant has reached are where the plan put them (rows: mask of the rollouts
+        that advance -- a terminated one is frozen)"""
         npr = self.nodes_per_replan
         for f in range(4):
             on = params[:, npr, f] > 0.5
+            if rows is not None:
+                on &= rows
             self.foot_pos[on, f] = params[on, npr, 4 + 3 * f:7 + 3 * f]
 
     def sim_step_rows(self, X: np.ndarray, params: np.ndarray, replan_index: int) -> np.ndarray:
@@ -244,72 +294,110 @@ class BatchedLocomotionMPC:
         push = {"start": s, "duration": s, "force": [B,3] N}: a base push applied to the plant as the
         velocity impulse F dt / m per replanning interval (the reference pushes the MuJoCo base,
         data_collection_force_perturbation.py:213-248).
+        `self.failed` [B] int32 (device): NMPC_ROLLOUT_FLAG_* bits of the recorded states, and above them 1 + the replan
+        that terminated the rollout (`terminate_mask`: frozen from then on, its solves skipped, rows repeated) -- the
+        same bookkeeping as `open_loop_device`.
         """
         x = np.array(x0, dtype=np.float64)
         n_replans = int(np.floor(trajectory_time / (self.replanning_steps * self.sim_dt) + 1e-9))
         dt_replan = self.replanning_steps * self.sim_dt
         rec, times = [], []
-        for i in range(n_replans):
-            t_now = i * dt_replan
-            self.set_convergence_on_first_iter()
-            X, _ = self.optimize(x)
-            self.first_solve = False
-            if self.record_sim_steps:
-                rec.append(self.sim_step_rows(X.double().cpu().numpy(), self._params, i))
-                times.extend(t_now + (np.arange(self.replanning_steps) + 1) * self.sim_dt)
-            else:
-                rec.append(self.record_state(x, t_now)[:, None, :])
-                times.append(t_now)
-            x = X[:, self.nodes_per_replan, :].double().cpu().numpy()          # plant = plan
-            if self.footsteps:
-                self.touch_down(self._params)
-            if push is not None and push["start"] <= t_now < push["start"] + push["duration"]:
-                x[:, 6:9] += np.asarray(push["force"]) * dt_replan / self.mp[1]
-            self.sim_step += self.replanning_steps
-            self.current_opt_node += self.nodes_per_replan
-            self.increment_base_ref_position(self.replanning_steps)
+        flags = np.zeros(self.batch, np.int32)
+        skip = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        self.solver.set_skip(skip, self.terminate_mask)
+        try:
+            for i in range(n_replans):
+                t_now = i * dt_replan
+                dead = (flags & self.terminate_mask) != 0
+                skip.copy_(torch.as_tensor(flags))
+                self.set_convergence_on_first_iter()
+                X, _ = self.optimize(x)
+                self.first_solve = False
+                st = self.status.cpu().numpy()
+                flags[~dead & ((st == 1) | (st == 4))] |= FLAG_SOLVER
+                if self.record_sim_steps:
+                    rows = self.sim_step_rows(X.double().cpu().numpy(), self._params, i)
+                    times.extend(t_now + (np.arange(self.replanning_steps) + 1) * self.sim_dt)
+                else:
+                    rows = self.record_state(x, t_now)[:, None, :]
+                    times.append(t_now)
+                if dead.any():
+                    rows[dead] = rec[-1][dead, -1:, :]
+                rec.append(rows)
+                flags[~dead] |= state_row_flags(rows[~dead], self.v_des[~dead], self.collision_height)
+                newly = ~dead & ((flags & self.terminate_mask) != 0)
+                flags[newly] |= (i + 1) << TERM_SHIFT
+                go = ~dead & ~newly                                                 # these advance: plant = plan
+                x_new = X[:, self.nodes_per_replan, :].double().cpu().numpy()
+                # (half a simulation step of slack on both ends of the window, as nmpc_rollout_batch: float-safe)
+                if push is not None and push["start"] - 0.5 * self.sim_dt <= t_now < push["start"] + push["duration"] - 0.5 * self.sim_dt:
+                    x_new[:, 6:9] += np.asarray(push["force"]) * dt_replan / self.mp[1]
+                x[go] = x_new[go]
+                if self.footsteps:
+                    self.touch_down(self._params, go)
+                self.sim_step += self.replanning_steps
+                self.current_opt_node += self.nodes_per_replan
+                self.increment_base_ref_position(self.replanning_steps, go)
+        finally:
+            self.solver.set_skip(None, 0)
         self._x_last = x
+        self.failed = torch.as_tensor(flags).to(self.device)
         S = torch.as_tensor(np.concatenate(rec, axis=1), dtype=torch.float32).to(self.device).contiguous()
         return S, np.asarray(times)
 
-    def open_loop_device(self, x0: np.ndarray, trajectory_time: float, push: Optional[dict] = None):
-        """`open_loop` with the whole rollout on the device: one C call launches every replanning
-        step (references, shift, solve, plant update) on the stream -- no host round trip per replan.
-        Same return value as `open_loop`; the controller state (X, U, node, reference) advances alike."""
+    def _rollout_cfg(self, n_replans: int, start_node: int, first_solve: bool, push: Optional[dict]):
         import ctypes
         from . import _lib
-        s, B, dev = self.solver, self.batch, self.device
-        dt_replan = self.replanning_steps * self.sim_dt
-        n_replans = int(np.floor(trajectory_time / dt_replan + 1e-9))
-        if self.foot_pos is None:
-            self.foot_pos = np.asarray(x0)[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]
-        period = self.config_gait.nominal_period
-        times = np.arange(n_replans) * dt_replan
-        phase = np.ascontiguousarray(np.round((times % period) / period, 4), dtype=np.float32)
-        cfg = _lib.NmpcRolloutCfg(
+        return _lib.NmpcRolloutCfg(
             n_replans, self.nodes_per_replan, self.replanning_steps, self.contact_planner.nodes_per_cycle,
-            self.current_opt_node, int(self.first_solve), N_SQP_FIRST, self.config_opt.nlp_tol / 10.0,
+            start_node, int(first_solve), N_SQP_FIRST, self.config_opt.nlp_tol / 10.0,
             self.config_opt.nlp_tol, self.sim_dt, self.config_opt.time_horizon, self.config_gait.nom_height,
             self.height_offset, float(push["start"]) if push else 0.0, float(push["duration"]) if push else 0.0,
             int(self.footsteps), int(self.record_sim_steps),
             (ctypes.c_float * 8)(*self.raibert.offset_hip_b[:, :2].ravel().tolist()),
             (ctypes.c_float * 4)(*np.asarray(self.config_gait.stance_ratio, float).tolist()),
-            float(period), float(self.raibert.foot_size))
+            float(self.config_gait.nominal_period), float(self.raibert.foot_size),
+            int(self.terminate_mask), float(self.collision_height))
+
+    def _device_rollout(self, n_replans, start_node, first_solve, push, x, v_des, w_des, ref_state, foot, X, U, status):
+        """One nmpc_rollout_batch call on explicit device tensors (x, ref_state, foot, X, U are updated in place).
+        Returns (S, failed)."""
+        import ctypes
+        from . import _lib
+        s, dev, B = self.solver, self.device, x.shape[0]
+        period = self.config_gait.nominal_period
+        times = np.arange(n_replans) * self.replanning_steps * self.sim_dt
+        phase = np.ascontiguousarray(np.round((times % period) / period, 4), dtype=np.float32)
+        cfg = self._rollout_cfg(n_replans, start_node, first_solve, push)
         rows_per_replan = self.replanning_steps if self.record_sim_steps else 1
-        gait = torch.as_tensor(np.ascontiguousarray(self.contact_planner.gait_sequence), dtype=torch.int8).to(dev)
-        x = s.to_device(x0)
-        v_des = torch.as_tensor(self.v_des, dtype=torch.float64).to(dev).contiguous()
-        w_des = torch.as_tensor(self.w_des, dtype=torch.float64).to(dev).contiguous()
-        ref_state = torch.as_tensor(self.base_ref_vel_tracking, dtype=torch.float64).to(dev).contiguous()
-        foot = s.to_device(self.foot_pos.reshape(B, 12))
+        if getattr(self, "_gait_dev", None) is None:
+            self._gait_dev = torch.as_tensor(np.ascontiguousarray(self.contact_planner.gait_sequence), dtype=torch.int8).to(dev)
         force = s.to_device(np.asarray(push["force"])) if push else None
         S = torch.empty(B, n_replans * rows_per_replan, 19, dtype=torch.float32, device=dev)
         failed = torch.zeros(B, dtype=torch.int32, device=dev)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(s.lib.nmpc_rollout_batch(
-            s._h, B, ctypes.byref(cfg), p(gait), p(x), p(v_des), p(w_des), p(ref_state), p(foot), p(force),
-            phase.ctypes.data_as(ctypes.c_void_p), p(self.X), p(self.U), p(S), p(self.status), p(failed),
+            s._h, B, ctypes.byref(cfg), p(self._gait_dev), p(x), p(v_des), p(w_des), p(ref_state), p(foot), p(force),
+            phase.ctypes.data_as(ctypes.c_void_p), p(X), p(U), p(S), p(status), p(failed),
             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), s._h, "nmpc_rollout_batch")
+        return S, failed
+
+    def open_loop_device(self, x0: np.ndarray, trajectory_time: float, push: Optional[dict] = None):
+        """`open_loop` with the whole rollout on the device: one C call launches every replanning
+        step (references, shift, solve, plant update) on the stream -- no host round trip per replan.
+        Same return value as `open_loop`; the controller state (X, U, node, reference) advances alike."""
+        s, B, dev = self.solver, self.batch, self.device
+        dt_replan = self.replanning_steps * self.sim_dt
+        n_replans = int(np.floor(trajectory_time / dt_replan + 1e-9))
+        if self.foot_pos is None:
+            self.foot_pos = np.asarray(x0)[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]
+        x = s.to_device(x0)
+        v_des = torch.as_tensor(self.v_des, dtype=torch.float64).to(dev).contiguous()
+        w_des = torch.as_tensor(self.w_des, dtype=torch.float64).to(dev).contiguous()
+        ref_state = torch.as_tensor(self.base_ref_vel_tracking, dtype=torch.float64).to(dev).contiguous()
+        foot = s.to_device(self.foot_pos.reshape(B, 12))
+        S, failed = self._device_rollout(n_replans, self.current_opt_node, self.first_solve, push, x, v_des, w_des, ref_state,
+                                         foot, self.X, self.U, self.status)
         # advance the host-side bookkeeping as open_loop does
         self.first_solve = False
         self.sim_step += n_replans * self.replanning_steps
@@ -319,9 +407,68 @@ class BatchedLocomotionMPC:
         self.x_final, self.failed = x, failed          # failed: NMPC_ROLLOUT_FLAG_* bits (include/nmpc.h)
         if self.footsteps:
             self.foot_pos = foot.cpu().numpy().astype(np.float64).reshape(B, 4, 3)
+        times = np.arange(n_replans) * dt_replan
         if self.record_sim_steps:
             times = (times[:, None] + (np.arange(self.replanning_steps) + 1) * self.sim_dt).ravel()
         return S, times
+
+    def open_loop_device_valid(self, x0: np.ndarray, trajectory_time: float, push_sampler, nominal=(0,), max_attempts: int = 8):
+        """Pushed rollouts with the reference's discard-and-redo: a rollout that terminates early is thrown away and rolled
+        again from the same initial state with a NEW push, until it runs to the end
+        (data_collection_pretrain_omini_vc_policy_1direction_perturbed.py:217-247, `while True: ... if not
+        early_termination: break`; RolloutMPC.py:424-437).  Here the whole batch rolls on the device, the rollouts whose
+        flags meet `invalid_mask` are gathered into a compacted batch, given new pushes and rolled again -- at most
+        `max_attempts` times in all (the reference loops without a cap); what is still invalid then keeps its flags and
+        gets no sampling weight in the learning update (parallel.learning_update).
+
+        push_sampler(n, attempt) -> {"start", "duration", "force": [n, 3]}; the rollouts listed in `nominal` are never
+        pushed (and never redone).  Call on a freshly reset controller.  Returns (S, t, info) with S, t as
+        `open_loop_device` and info = {"attempt_sizes": rollouts run per attempt, "first_attempt": flag counts of the first
+        pass}; `self.failed`, `self.x_final`, `self.X`, `self.U`, `self.foot_pos` hold the kept rollouts."""
+        assert self.first_solve and self.current_opt_node == 0, "open_loop_device_valid starts from a reset controller"
+        s, B, dev = self.solver, self.batch, self.device
+        nominal = np.asarray(nominal, dtype=np.int64)
+        x0 = np.asarray(x0, dtype=np.float64)
+        ref0 = self.base_ref_vel_tracking.copy()
+        foot0 = (self.foot_pos if self.foot_pos is not None else x0[:, None, :3] * [1, 1, 0] + HIP_OFFSETS[None]).copy()
+        push = push_sampler(B, 0)
+        force = np.array(push["force"], dtype=np.float64)
+        force[nominal] = 0.0
+        S, times = self.open_loop_device(x0, trajectory_time, dict(push, force=force))
+        n_replans = int(np.floor(trajectory_time / (self.replanning_steps * self.sim_dt) + 1e-9))
+        f0 = self.failed
+        count = lambda bit: int((f0 & bit).ne(0).sum().item())
+        info = {"attempt_sizes": [B],
+                "first_attempt": {"invalid": count(self.invalid_mask), "solver": count(FLAG_SOLVER), "collision": count(FLAG_COLLISION),
+                                  "roll": count(FLAG_ROLL), "pitch": count(FLAG_PITCH), "height": count(FLAG_HEIGHT),
+                                  "velocity_tracking": count(FLAG_VEL_TRACKING)}}
+        keep = torch.ones(B, dtype=torch.bool, device=dev)
+        keep[torch.as_tensor(nominal, device=dev)] = False
+        for attempt in range(1, max_attempts):
+            idx = torch.nonzero((self.failed & self.invalid_mask).ne(0) & keep).flatten()
+            n = int(idx.numel())                                   # (the one host round trip of an attempt)
+            if n == 0:
+                break
+            idx_h = idx.cpu().numpy()
+            push_n = push_sampler(n, attempt)
+            x = s.to_device(x0[idx_h])
+            v_des = torch.as_tensor(self.v_des[idx_h], dtype=torch.float64).to(dev).contiguous()
+            w_des = torch.as_tensor(self.w_des[idx_h], dtype=torch.float64).to(dev).contiguous()
+            ref_state = torch.as_tensor(ref0[idx_h], dtype=torch.float64).to(dev).contiguous()
+            foot = s.to_device(foot0[idx_h].reshape(n, 12))
+            Xn = torch.zeros(n, self.n_nodes + 1, 12, dtype=torch.float32, device=dev)
+            Un = torch.zeros(n, self.n_nodes, 12, dtype=torch.float32, device=dev)
+            stn = torch.zeros(n, dtype=torch.int32, device=dev)
+            Sn, failed_n = self._device_rollout(n_replans, 0, True, push_n, x, v_des, w_des, ref_state, foot, Xn, Un, stn)
+            S[idx] = Sn
+            self.failed[idx] = failed_n
+            self.x_final[idx] = x
+            self.X[idx] = Xn; self.U[idx] = Un; self.status[idx] = stn
+            self.base_ref_vel_tracking[idx_h] = ref_state.cpu().numpy()
+            if self.footsteps:
+                self.foot_pos[idx_h] = foot.cpu().numpy().astype(np.float64).reshape(n, 4, 3)
+            info["attempt_sizes"].append(n)
+        return S, times, info
 
     def record_state(self, x: np.ndarray, t: float) -> np.ndarray:
         period = self.config_gait.nominal_period

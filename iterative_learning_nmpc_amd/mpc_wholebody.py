@@ -27,7 +27,7 @@ from .config import get_quadruped_config
 from .contact_planner import ContactPlanner, RaiberContactPlanner
 from .profiling import print_timings, time_fn
 from .quadruped_solver import QuadrupedAcadosSolver
-from .references import base_ref_vel_tracking, hermite_upsample, increment_base_ref_position
+from .references import base_ref_cnt_restricted, base_ref_vel_tracking, hermite_upsample, increment_base_ref_position
 from .workloads import FEET
 
 N_SQP_FIRST = 15     # mpc.py:465
@@ -38,7 +38,7 @@ class LocomotionMPC:
                  joint_ref: Optional[np.ndarray] = None, interactive_goal: bool = False, sim_dt: float = 1.0e-3,
                  height_offset: float = 0., contact_planner: str = "", print_info: bool = True,
                  compute_timings: bool = True, solve_async: bool = False, batch: int = 1, device="cuda:0",
-                 n_nodes: Optional[int] = None):
+                 n_nodes: Optional[int] = None, force_reference: str = "zero"):
         self.batch = int(batch)
         self.config_gait, self.config_opt, self.config_cost = get_quadruped_config(gait_name, robot_name)
         if n_nodes is not None:                      # BASELINE configs[2] asks for N = 30; the reference runs 25
@@ -46,7 +46,8 @@ class LocomotionMPC:
         self.print_info = print_info
         self.height_offset = height_offset
         self.solver = QuadrupedAcadosSolver(path_urdf, list(feet_frame_names), self.config_opt, self.config_cost,
-                                            height_offset, print_info, compute_timings, batch=batch, device=device)
+                                            height_offset, print_info, compute_timings, batch=batch, device=device,
+                                            force_reference=force_reference)
         self.nq, self.nv, self.nu, self.n_foot = 18, 18, wb.N_JOINTS, 4
         self.joint_ref = np.asarray(joint_ref, float) if joint_ref is not None else wb.Q_HOME.copy()   # mpc.py:73-81
         self._contact_planner_str = contact_planner
@@ -104,36 +105,23 @@ class LocomotionMPC:
         return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
 
     def compute_base_ref_cnt_restricted(self, q, contact_locations):                        # mpc.py:274-315
-        """base references from a contact-location plan [4, N+1, 3]: centres of the first and the last complete set of
-        planned (non-zero) locations"""
-        cnt_loc = np.unique(contact_locations, axis=1)
-        id_non_zero = np.argwhere(np.all(cnt_loc != np.zeros(3), axis=-1))
-        bin_count = np.bincount(id_non_zero[:, 1])
-        if len(bin_count) > 0:
-            id_first = np.argmax(bin_count)
-            id_last = len(bin_count) - np.argmax(bin_count[::-1]) - 1
-            center_first, center_last = np.mean(cnt_loc[:, id_first, :], axis=0), np.mean(cnt_loc[:, id_last, :], axis=0)
-        else:
-            center_first, center_last = np.mean(contact_locations[:, 0, :], axis=0), np.mean(contact_locations[:, -1, :], axis=0)
-        base_ref, base_ref_e = np.zeros(12), np.zeros(12)
-        alpha = 0.35
-        base_ref[:2] = alpha * center_first[:2] + (1 - alpha) * center_last[:2]
-        base_ref_e[:2] = center_last[:2]
-        base_ref[2] = base_ref_e[2] = self.config_gait.nom_height + self.height_offset
-        return base_ref, base_ref_e
+        return base_ref_cnt_restricted(contact_locations, self.config_gait.nom_height, self.height_offset)
 
     def _replan(self) -> bool:                                                              # mpc.py:171-175
         return self.sim_step % self.replanning_steps == 0
 
     def set_convergence_on_first_iter(self):                                                # mpc.py:464-473
+        """iteration policy of the solve about to run: the first one gets N_SQP_FIRST SQP iterations at a tenth of the
+        configured tolerances; the configured policy is restored during the first replanning interval after it"""
+        cfg = self.solver.config_opt
         if self.first_solve:
-            self.solver.set_max_iter(N_SQP_FIRST)
-            self.solver.set_nlp_tol(self.solver.config_opt.nlp_tol / 10.)
-            self.solver.set_qp_tol(self.solver.config_opt.qp_tol / 10.)
+            policy = (N_SQP_FIRST, cfg.nlp_tol / 10., cfg.qp_tol / 10.)
         elif self.sim_step <= self.replanning_steps:
-            self.solver.set_max_iter(self.solver.config_opt.max_iter)
-            self.solver.set_nlp_tol(self.solver.config_opt.nlp_tol)
-            self.solver.set_qp_tol(self.solver.config_opt.qp_tol)
+            policy = (cfg.max_iter, cfg.nlp_tol, cfg.qp_tol)
+        else:
+            return
+        for setter, value in zip((self.solver.set_max_iter, self.solver.set_nlp_tol, self.solver.set_qp_tol), policy):
+            setter(value)
 
     def solver_inputs(self, q: np.ndarray, v: np.ndarray):
         """what `optimize` hands to `solver.init` (mpc.py:325-366), without solving"""

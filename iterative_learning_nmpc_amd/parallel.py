@@ -12,7 +12,7 @@ reduces them with the tracking-error / OOD rule
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -75,8 +75,25 @@ def ood_threshold(n_state: int) -> float:
     return OOD_THRESHOLD_REFERENCE * ((n_state - 1) / 43.0) ** 0.5
 
 
-def learning_update(err_all: torch.Tensor, threshold: float = 4.0, ood_weight: float = 5.0):
-    """OOD mask and sampling weights from the gathered errors (identical on every rank)."""
-    ood = err_all > threshold
+def all_gather_validity(valid_local: torch.Tensor, total: int) -> torch.Tensor:
+    """The ranks' per-rollout validity flags (bool [B_local]: the rollout ran to the end, nothing in it was discarded) as
+    one bool [total] in rollout order -- rides the same exchange as the errors, so that every rank masks the same
+    rollouts in the update."""
+    return all_gather_tracking_errors(valid_local.to(torch.float32).unsqueeze(1), total).squeeze(1) > 0.5
+
+
+def learning_update(err_all: torch.Tensor, threshold: float = 4.0, ood_weight: float = 5.0,
+                    valid: Optional[torch.Tensor] = None):
+    """OOD mask and sampling weights from the gathered errors (identical on every rank).
+
+    valid: bool [total] per rollout -- a rollout that was terminated early and could not be redone is not data: the
+    reference deletes its file (RolloutMPC.py:432-435), here it gets sampling weight 0 and is never out-of-distribution.
+    A non-finite error (a rollout whose solver failed) is treated the same way whether or not `valid` says so -- compared
+    with the threshold it would silently read as in-distribution, weight 1."""
+    ok = torch.isfinite(err_all)
+    if valid is not None:
+        ok = ok & valid.reshape(-1, *([1] * (err_all.dim() - 1)))
+    ood = (err_all > threshold) & ok
     weights = torch.where(ood, err_all.new_full((), ood_weight), err_all.new_ones(()))
+    weights = torch.where(ok, weights, err_all.new_zeros(()))
     return ood, weights

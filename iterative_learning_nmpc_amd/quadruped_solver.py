@@ -17,14 +17,19 @@ Below the class sits `libnmpc_hip.so` (include/nmpc.h, model NMPC_MODEL_WHOLEBOD
 packs them into the batch-major device tensors of the C-ABI and `solve` unpacks the result.  A leading batch axis
 (`batch > 1`) turns every view into `[B, dim, nodes]` and every `init` argument into its batched form.
 
-Declared differences:
+Declared differences (`UNSUPPORTED` lists what a caller may have switched on and does not get):
   * `path_urdf` is accepted and not read: pinocchio / the URDF are not in the image, the model is the declared
     quadruped of `wholebody.py` (geometry of `workloads.quadruped_tree()`);
   * the names of the views that come from the absent `contact_tamp` are declared here (`NAMES`);
-  * `restrict`, `range_radius`, `plane_normal` and the `pos_cost` references are kept in the views for callers and
-    visualisers (main.py:24-36) but the declared model uses the plane point's height and e_z only;
-  * the force regularisation refers to the gravity share of the stance feet (`force_reference="gravity_share"`,
-    as BASELINE configs[1]) unless `force_reference="zero"` is asked for;
+  * contact-restricted mode (`set_contact_restriction(True)`, the Raibert planner): the foot-placement cost `pos_cost`
+    (x, y of each foot against the planned location, weight `W_foot_displacement`, solver.py:128-137,272-273) IS part of
+    the solved model; the hard patch constraint behind `restrict` / `range_radius` (|p_xy - plane_point_xy| <= cnt_radius
+    at touch-down nodes, inside contact_tamp) is NOT -- the views are kept, a warning is issued once;
+  * `config_opt.torque_limit` (default True, config_abstract.py:68): joint-torque bounds are state-dependent general
+    inequalities tau(q, a, f); the interior point of this build carries input inequalities only -- not enforced, warned;
+  * the force regularisation refers to ZERO force as the reference's (solver.py:128-130); `force_reference="gravity_share"`
+    regularises to the weight share of the stance feet instead (what the synthetic workloads of BASELINE configs[1] / [2]
+    use: with this build's soft stance penalty a zero reference lets the base sag);
   * `warm_start_multipliers` has no counterpart: the interior point cold-starts every SQP iteration; `qp_tol` is
     stored, the interior point runs `max_qp_iter` iterations.
 """
@@ -92,16 +97,22 @@ class QuadrupedAcadosSolver:
 
     def __init__(self, path_urdf: str, feet_frame_names: List[str], config_opt, config_cost,
                  height_offset: float = 0., print_info: bool = False, compute_timings: bool = True,
-                 batch: int = 1, device="cuda:0", force_reference: str = "gravity_share",
-                 w_contact: float = W_CONTACT, w_consistency: float = W_CONSISTENCY):
+                 batch: int = 1, device="cuda:0", force_reference: str = "zero",
+                 w_contact: float = W_CONTACT, w_consistency: float = W_CONSISTENCY, strict: bool = False):
         self.feet_frame_names = list(feet_frame_names)
         assert len(self.feet_frame_names) == 4, "the declared model is a quadruped"
         self.config_opt, self.config_cost = config_opt, config_cost
         self.height_offset, self.print_info = height_offset, print_info
         self.restrict_cnt = False
         self.batch, self.device = int(batch), device
+        assert force_reference in ("zero", "gravity_share")
         self.force_reference = force_reference
         self.w_contact, self.w_consistency = float(w_contact), float(w_consistency)
+        # what the configuration asks for and this build does not enforce (module docstring); strict: raise instead of warn
+        self.strict, self.unsupported = bool(strict), []
+        if getattr(self.config_opt, "torque_limit", False):
+            self._unsupported("torque_limit", "config_opt.torque_limit is set (the reference's default): joint-torque limits are not "
+                              "enforced by this solver (input inequalities only); set torque_limit=False to acknowledge")
         self.dt_nodes = self.config_opt.get_dt_nodes()
         self.enable_time_opt = self.config_opt.enable_time_opt
         assert not self.enable_time_opt, "time optimisation (dt as an input) is not part of the declared model"
@@ -115,6 +126,15 @@ class QuadrupedAcadosSolver:
         self._dev = None                      # BatchedNmpcSolver, created at the first solve (needs the GPU)
         self._dims = MODEL_DIMS[MODEL_WHOLEBODY]
         self.reset()
+
+    def _unsupported(self, key: str, msg: str):
+        if key in self.unsupported:
+            return
+        self.unsupported.append(key)
+        if self.strict:
+            raise NotImplementedError(msg)
+        import warnings
+        warnings.warn(f"QuadrupedAcadosSolver (MI355X): {msg}", UserWarning, stacklevel=3)
 
     # ------------------------------------------------------------------------------------------ views
     def _shape(self, *s):
@@ -190,6 +210,10 @@ class QuadrupedAcadosSolver:
 
     def set_contact_restriction(self, restrict: bool = True):                               # solver.py:100-103
         self.restrict_cnt = restrict
+        if restrict and self.config_cost.cnt_radius < 1.0e9:
+            self._unsupported("patch_restriction", f"contact restriction: the foot-placement cost (W_foot_displacement = "
+                              f"{float(self.config_cost.W_foot_displacement[0]):g}) is solved, the hard patch constraint of radius "
+                              f"{self.config_cost.cnt_radius} m behind `restrict` / `range_radius` is not")
         self.set_cost_weights()
 
     def update_cost(self, config_cost):                                                     # solver.py:105-110
@@ -213,11 +237,16 @@ class QuadrupedAcadosSolver:
         """the weight vectors of the C-ABI in its residual order (include/nmpc.h)"""
         d = self.dyn
         W, W_e = self.data["W"], self.data["W_e"]
+        # foot placement: the model carries x, y of each foot (8 rows); the reference never weights z (solver.py:133-134)
+        for f in d.feet:
+            assert W[f.pos_cost.name][2] == 0 and W_e[f.pos_cost.name][2] == 0, "pos_cost: only x, y are part of the model"
         self._W = np.concatenate([W[d.base_cost.name], W[d.joint_cost.name], W[d.acc_cost.name], W[d.swing_cost.name],
                                   np.concatenate([W[f.f_reg.name] for f in d.feet]),
-                                  np.full(12, self.w_contact), np.full(6, self.w_consistency)])
+                                  np.full(12, self.w_contact), np.full(6, self.w_consistency),
+                                  np.concatenate([W[f.pos_cost.name][:2] for f in d.feet])])
         self._W_e = np.concatenate([W_e[d.base_cost.name], W_e[d.joint_cost.name], W_e[d.swing_cost.name],
-                                    np.full(12, self.w_contact), np.full(6, self.w_consistency)])
+                                    np.full(12, self.w_contact), np.full(6, self.w_consistency),
+                                    np.concatenate([W_e[f.pos_cost.name][:2] for f in d.feet])])
         if self._dev is not None:
             self._dev.set_cost_weights(self._W, self._W_e, self.config_cost.reg_eps, self.config_cost.reg_eps_e)
 
@@ -336,7 +365,7 @@ class QuadrupedAcadosSolver:
         return a if self.batch > 1 else a[None]
 
     def pack_problem(self) -> Dict[str, np.ndarray]:
-        """the dict views as the batch-major arrays of the C-ABI: x0[B,42], yref[B,N,82], yref_e[B,58],
+        """the dict views as the batch-major arrays of the C-ABI: x0[B,42], yref[B,N,90], yref_e[B,66],
         params[B,N+1,20], X[B,N+1,42], U[B,N,30] (what `update_solver` hands to the solver, solver.py:345-353)"""
         d, N, B = self.dyn, self.config_opt.n_nodes, self.batch
         t = lambda a: np.swapaxes(self._b(a), -1, -2)                                       # [B, nodes, dim]
@@ -351,11 +380,13 @@ class QuadrupedAcadosSolver:
             n_st = np.maximum(act[:, :N].sum(-1, keepdims=True), 1.0)
             f_ref = f_ref.copy()
             f_ref[:, :, 2::3] += act[:, :N] * (-self.mp[5] * self.mp[1]) / n_st
+        pos_ref = np.concatenate([t(self.cost_ref[f.pos_cost.name])[..., :2] for f in d.feet], axis=-1)        # [B, N, 8]
+        pos_ref_e = np.concatenate([self._b(self.cost_ref_terminal[f.pos_cost.name])[..., :2] for f in d.feet], axis=-1)
         yref = np.concatenate([t(self.cost_ref[d.base_cost.name]), t(self.cost_ref[d.joint_cost.name]),
                                t(self.cost_ref[d.acc_cost.name]), t(self.cost_ref[d.swing_cost.name]), f_ref,
-                               np.zeros((B, N, 18))], axis=-1)
+                               np.zeros((B, N, 18)), pos_ref], axis=-1)
         yref_e = np.concatenate([self._b(self.cost_ref_terminal[d.base_cost.name]), self._b(self.cost_ref_terminal[d.joint_cost.name]),
-                                 self._b(self.cost_ref_terminal[d.swing_cost.name]), np.zeros((B, 18))], axis=-1)
+                                 self._b(self.cost_ref_terminal[d.swing_cost.name]), np.zeros((B, 18)), pos_ref_e], axis=-1)
         return dict(x0=self._b(self._x0), yref=yref, yref_e=yref_e, params=params, X=X, U=U)
 
     @time_fn("update_solver")
@@ -386,16 +417,36 @@ class QuadrupedAcadosSolver:
             self._push_opts()
         return self._dev
 
+    def _buffers(self):
+        """device tensors of the problem and pinned host mirrors, allocated once: a solve is six asynchronous uploads, the
+        kernels, four asynchronous downloads and ONE stream synchronisation (the caller reads the numpy views right away)"""
+        import torch
+        if getattr(self, "_dbuf", None) is None:
+            s = self._device_solver()
+            p = self._problem
+            self._hbuf = {k: torch.empty(p[k].shape, dtype=torch.float32).pin_memory() for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+            self._dbuf = {k: torch.empty(p[k].shape, dtype=torch.float32, device=s.device) for k in self._hbuf}
+            self._dbuf["status"] = torch.empty(self.batch, dtype=torch.int32, device=s.device)
+            self._dbuf["stats"] = torch.empty(self.batch, 4, dtype=torch.float32, device=s.device)
+            self._hbuf["status"] = torch.empty(self.batch, dtype=torch.int32).pin_memory()
+            self._hbuf["stats"] = torch.empty(self.batch, 4, dtype=torch.float32).pin_memory()
+        return self._hbuf, self._dbuf
+
     @time_fn("solve")
     def solve(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:   # solver.py:396-429
         import torch
         s = self._device_solver()
         p = self._problem
-        t = {k: s.to_device(p[k]) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
-        X, U, status, stats = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"])
-        torch.cuda.synchronize()
-        self.status, self.stats = status.cpu().numpy(), stats.cpu().numpy()
-        self.parse_sol(X.cpu().numpy().astype(np.float64), U.cpu().numpy().astype(np.float64))
+        h, d = self._buffers()
+        for k in ("x0", "yref", "yref_e", "params", "X", "U"):
+            h[k].numpy()[...] = p[k]
+            d[k].copy_(h[k], non_blocking=True)
+        s.solve(d["x0"], d["yref"], d["yref_e"], d["params"], d["X"], d["U"], d["status"], d["stats"])
+        for k in ("X", "U", "status", "stats"):
+            h[k].copy_(d[k], non_blocking=True)
+        torch.cuda.current_stream(s.device).synchronize()
+        self.status, self.stats = h["status"].numpy().copy(), h["stats"].numpy().copy()
+        self.parse_sol(h["X"].numpy().astype(np.float64), h["U"].numpy().astype(np.float64))
         return self.q_sol_euler, self.v_sol_euler, self.a_sol, self.f_sol, self.dt_node_sol
 
     def parse_sol(self, X: np.ndarray, U: np.ndarray):

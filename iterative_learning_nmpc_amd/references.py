@@ -8,6 +8,7 @@ Restates (numerically identical, golden vectors in tests/golden/):
   increment_base_ref_position           mpc.py:204-208
   hermite_upsample                      interpolate_trajectory_with_derivatives, mpc.py:388-414
   zero_order_hold_index                 id_repeat, mpc.py:142
+  base_ref_cnt_restricted               LocomotionMPC.compute_base_ref_cnt_restricted, mpc.py:274-315
 """
 from __future__ import annotations
 
@@ -121,3 +122,29 @@ def hermite_upsample(time_traj, positions, velocities, accelerations, n_interp: 
 def zero_order_hold_index(n_interp: int, n_nodes: int) -> np.ndarray:
     """Node index held at each interpolated sample (mpc.py:142)."""
     return np.int32(np.linspace(0, 1, n_interp) * (n_nodes - 1))
+
+
+def base_ref_cnt_restricted(contact_locations, nom_height: float, height_offset: float = 0.0,
+                            blend: float = 0.35) -> Tuple[np.ndarray, np.ndarray]:
+    """Running and terminal base references of the contact-restricted mode (Raibert plan in hand): the base is sent
+    between the centre of the first and the centre of the last COMPLETE set of planned foot locations.
+
+    contact_locations [4, N+1, 3]: the plan, all-zero where a foot has no planned location yet.  The distinct location
+    sets are taken in numpy's sorted order (`np.unique(.., axis=1)`), a set counts a foot when all three coordinates of
+    that foot are non-zero, and "complete" means "as many feet as the best set has" -- the reference's bincount/argmax
+    construction, quirks included: its sets are sorted by value, not by time, so "first"/"last" are the extremes of that
+    order.  Running reference: 0.35 first + 0.65 last in x, y; terminal: the last centre; height as configured; everything
+    else zero.  Pinned by tests/golden/cnt_restricted.npz (the reference's own outputs)."""
+    loc = np.asarray(contact_locations, float)
+    sets = np.unique(loc, axis=1)                                   # [4, n_sets, 3]
+    feet_planned = np.all(sets != 0.0, axis=-1).sum(axis=0)         # per set: feet with a location
+    if feet_planned.any():
+        best = np.flatnonzero(feet_planned == feet_planned.max())
+        first, last = sets[:, best[0]].mean(axis=0), sets[:, best[-1]].mean(axis=0)
+    else:                                                           # nothing planned at all: first and last node as they are
+        first, last = loc[:, 0].mean(axis=0), loc[:, -1].mean(axis=0)
+    ref, ref_e = np.zeros(12), np.zeros(12)
+    ref[:2] = blend * first[:2] + (1.0 - blend) * last[:2]
+    ref_e[:2] = last[:2]
+    ref[2] = ref_e[2] = nom_height + height_offset
+    return ref, ref_e

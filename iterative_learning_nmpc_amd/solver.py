@@ -98,6 +98,15 @@ class BatchedNmpcSolver:
         _lib.check(self.lib.nmpc_set_contact_patterns(self._h, int(bool(all_patterns))), self._h, "nmpc_set_contact_patterns")
         return bool(all_patterns)
 
+    def set_skip(self, flags: Optional[torch.Tensor], mask: int = 0):
+        """Leave problems out of the following solves: flags int32 [batch_max] on the device (kept alive by the caller
+        and by this object), a problem with flags[b] & mask != 0 is skipped -- X, U, status untouched, no time spent
+        (terminated rollouts).  None detaches.  The flags are read when the kernels run."""
+        if flags is not None:
+            self._chk(flags, (self.batch_max,), "flags", torch.int32)
+        self._skip_flags = flags
+        _lib.check(self.lib.nmpc_set_skip(self._h, _ptr(flags), int(mask)), self._h, "nmpc_set_skip")
+
     def set_ipm(self, mu0=10.0, sigma=0.2, s_min=1.0, gamma=0.995, tau_min=0.1, merit_rho=1e3):
         _lib.check(self.lib.nmpc_set_ipm(self._h, mu0, sigma, s_min, gamma, tau_min, merit_rho),
                    self._h, "nmpc_set_ipm")

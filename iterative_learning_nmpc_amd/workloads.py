@@ -28,7 +28,7 @@ MODEL_CENTROIDAL = 1
 MODEL_WHOLEBODY = 2
 MODEL_DIMS = {MODEL_DOUBLE_INTEGRATOR: dict(nx=4, nu=2, np=0, ng=4, ny=6, ny_e=4),
               MODEL_CENTROIDAL: dict(nx=12, nu=12, np=16, ng=16, ny=24, ny_e=12),
-              MODEL_WHOLEBODY: dict(nx=42, nu=30, np=20, ng=16, ny=82, ny_e=58)}
+              MODEL_WHOLEBODY: dict(nx=42, nu=30, np=20, ng=16, ny=90, ny_e=66)}
 
 # model parameter vector (shared layout with include/nmpc.h: NMPC_MP_*)
 MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax",
@@ -134,13 +134,15 @@ def centroidal_trot(B: int = 1024, N: int = 50, seed: int = 0, warm: str = "stan
                          reg=cost.reg_eps, reg_e=cost.reg_eps_e))
 
 
-def wholebody_weights(cost, w_contact: float = W_CONTACT, w_consistency: float = W_CONSISTENCY):
-    """W[82], W_e[58] of the whole-body model in the residual order of include/nmpc.h: base, joint, acc, swing,
-    f_reg, contact, consistency / base, joint, swing, contact, consistency (solver.py:108-141)."""
+def wholebody_weights(cost, w_contact: float = W_CONTACT, w_consistency: float = W_CONSISTENCY, w_foot_displacement: float = 0.0):
+    """W[90], W_e[66] of the whole-body model in the residual order of include/nmpc.h: base, joint, acc, swing,
+    f_reg, contact, consistency, foot placement / base, joint, swing, contact, consistency, foot placement
+    (solver.py:108-141).  w_foot_displacement: the pos_cost weight on x, y of every foot -- 0 outside the reference's
+    contact-restricted mode, `cost.W_foot_displacement[0]` inside it (solver.py:131-137)."""
     W = np.concatenate([cost.W_base, cost.W_joint, cost.W_acc, cost.W_swing, np.asarray(cost.W_cnt_f_reg).ravel(),
-                        np.full(12, w_contact), np.full(6, w_consistency)])
+                        np.full(12, w_contact), np.full(6, w_consistency), np.full(8, w_foot_displacement)])
     W_e = np.concatenate([cost.W_e_base, cost.W_e_joint, cost.W_swing, np.full(12, w_contact),
-                          np.full(6, w_consistency)])
+                          np.full(6, w_consistency), np.full(8, w_foot_displacement)])
     return W, W_e
 
 
@@ -159,12 +161,14 @@ def anchor_plane_points(contacts: np.ndarray, feet_w: np.ndarray, height_offset:
     return pp
 
 
-def wholebody_trot(B: int = 8192, N: int = 30, seed: int = 0, sigma_joint: float = 0.2) -> Workload:
+def wholebody_trot(B: int = 8192, N: int = 30, seed: int = 0, sigma_joint: float = 0.2, foot_placement: float = 0.0) -> Workload:
     """BASELINE configs[2]: whole-body 18-DoF quadruped, nx = 42, nu = 30, trot, T = 1.0 s.
 
     x0: base as config 2, joints q_home + N(0, sigma_joint) (DAgger/cfgs: sigma_joint_pos 0.2), joint rates
     N(0, 0.2), momentum slots consistent with (q, v) as the reference's `pin_data.hg` (solver.py:187).  Warm start:
-    the state held, a = 0, every stance foot carrying an equal share of the weight."""
+    the state held, a = 0, every stance foot carrying an equal share of the weight.
+    foot_placement > 0: the reference's contact-restricted cost (pos_cost, solver.py:128-137) with that weight on x, y of
+    every foot, against a synthetic plan -- the nominal foothold under each hip carried along with the commanded velocity."""
     from . import wholebody as wb
     rng = np.random.default_rng(seed)
     gait, opt, cost = get_quadruped_config("trot", "go2")
@@ -210,7 +214,15 @@ def wholebody_trot(B: int = 8192, N: int = 30, seed: int = 0, sigma_joint: float
     yref[:, :, 48:52] = gait.step_height           # swing-height reference (solver.py:170)
     yref_e[:, 12:24] = wb.Q_HOME
     yref_e[:, 36:40] = gait.step_height
-    W, W_e = wholebody_weights(cost)
+    W, W_e = wholebody_weights(cost, w_foot_displacement=foot_placement)
+    if foot_placement > 0.0:
+        cy, sy = np.cos(q0[:, 3]), np.sin(q0[:, 3])
+        hip_w = q0[:, None, :2] + np.stack([cy[:, None] * HIP_OFFSETS[None, :, 0] - sy[:, None] * HIP_OFFSETS[None, :, 1],
+                                            sy[:, None] * HIP_OFFSETS[None, :, 0] + cy[:, None] * HIP_OFFSETS[None, :, 1]], axis=-1)   # [B, 4, 2]
+        t_k = (np.arange(N + 1) + 0.0) * dt
+        plan = hip_w[:, None] + v_des[:, None, None, :2] * t_k[None, :, None, None]                                       # [B, N+1, 4, 2]
+        yref[:, :, 82:90] = plan[:, 1:].reshape(B, N, 8)          # stage k refers to the location at node k + 1 (solver.py:272)
+        yref_e[:, 58:66] = plan[:, -1].reshape(B, 8)
     X = np.repeat(x0[:, None, :], N + 1, axis=1)
     U = np.zeros((B, N, d["nu"]))
     n_stance = np.maximum(contacts[:, :, :N].sum(1), 1.0)

@@ -84,7 +84,7 @@
  *           (0,0,-l1), point foot at (0,0,-l2) -- the declared tree of workloads.quadruped_tree();
  *           single-rigid-body inertia for the momentum map: A_g(q) v = [m rdot; R I_b E(th) thdot],
  *           E = euler_derivative_to_local_angular (transform.py:80-86), COM at the base origin.
- *           Gauss-Newton least-squares cost, residuals and weights in this order (ny = 82):
+ *           Gauss-Newton least-squares cost, residuals and weights in this order (ny = 90):
  *             base(12)   [q[0:6], v[0:6]] - base_ref          W_base      dynamics.py:121-124
  *             joint(24)  [q[6:], v[6:]] - [joint_ref, 0]      W_joint     dynamics.py:126, solver.py:175-177
  *             acc(12)    a[6:]                                W_acc       dynamics.py:129
@@ -95,7 +95,7 @@
  *                        (solver.py:219, mpc_cost.py:60), entering as a quadratic penalty: the
  *                        Riccati/IPM core of this build carries input inequalities only
  *             consist(6) h - A_g(q) v                                               [decl weight]
- *           terminal (ny_e = 58): base (W_e_base), joint (W_e_joint), swing, contact, consist.
+ *           terminal (ny_e = 66): base (W_e_base), joint (W_e_joint), swing, contact, consist, pos.
  *           friction pyramid on f as in model 1 (ng = 16).
  */
 #include <math.h>
@@ -143,7 +143,7 @@ int oracle_dims(int model_id, int *nx, int *nu, int *np, int *ng) {
 int oracle_output_dims(int model_id, int *ny, int *nye) {
     int nx, nu, np, ng;
     if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
-    if (model_id == 2) { *ny = 82; *nye = 58; return 0; }
+    if (model_id == 2) { *ny = 90; *nye = 66; return 0; }
     *ny = nx + nu; *nye = nx;
     return 0;
 }
@@ -349,10 +349,10 @@ static void dyn_centroidal(const real *mp, const real *x, const real *u, const r
 }
 
 /* ------------------------------------------------------------------ model 2 (whole body) */
-enum { WB_NX = 42, WB_NU = 30, WB_NP = 20, WB_NG = 16, WB_NY = 82, WB_NYE = 58 };
+enum { WB_NX = 42, WB_NU = 30, WB_NP = 20, WB_NG = 16, WB_NY = 90, WB_NYE = 66 };
 enum { WQ = 0, WV = 18, WH = 36, WA = 0, WF = 18 };                    /* state / input offsets */
-enum { RY_BASE = 0, RY_JOINT = 12, RY_ACC = 36, RY_SWING = 48, RY_FREG = 52, RY_CNT = 64, RY_CONS = 76 };
-enum { RE_BASE = 0, RE_JOINT = 12, RE_SWING = 36, RE_CNT = 40, RE_CONS = 52 };
+enum { RY_BASE = 0, RY_JOINT = 12, RY_ACC = 36, RY_SWING = 48, RY_FREG = 52, RY_CNT = 64, RY_CONS = 76, RY_POS = 82 };
+enum { RE_BASE = 0, RE_JOINT = 12, RE_SWING = 36, RE_CNT = 40, RE_CONS = 52, RE_POS = 58 };
 
 static void m3_vec(const real *a, const real *v, real *o) { /* o = a v */
     for (int i = 0; i < 3; i++) o[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
@@ -521,6 +521,7 @@ static void wb_residuals(const real *mp, const real *x, const real *u, const rea
     const int nx = WB_NX, term = (u == NULL);
     const int ny = term ? WB_NYE : WB_NY;
     const int r_sw = term ? RE_SWING : RY_SWING, r_ct = term ? RE_CNT : RY_CNT, r_cs = term ? RE_CONS : RY_CONS;
+    const int r_ps = term ? RE_POS : RY_POS;
     wb_kin_t k;
     wb_kinematics(mp, x, 1, &k);
     if (Jx) memset(Jx, 0, sizeof(real) * ny * nx);
@@ -545,9 +546,12 @@ static void wb_residuals(const real *mp, const real *x, const real *u, const rea
         for (int i = 0; i < 3; i++)
             for (int cc = 0; cc < 9; cc++) vel[i] += k.J[f][9 * i + cc] * x[WV + wb_xi(f, cc)];
         for (int i = 0; i < 3; i++) res[r_ct + 3 * f + i] = c * (vel[i] + (i == 2 ? pg * (k.p[f][2] - ppz) : 0));
+        /* foot placement (pos_cost, solver.py:128-137,272-273): world x, y of the foot against the planned location */
+        for (int i = 0; i < 2; i++) res[r_ps + 2 * f + i] = k.p[f][i];
         if (Jx)
             for (int cc = 0; cc < 9; cc++) {
                 const int col = wb_xi(f, cc);
+                for (int i = 0; i < 2; i++) Jx[(r_ps + 2 * f + i) * nx + WQ + col] = k.J[f][9 * i + cc];
                 Jx[(r_sw + f) * nx + WQ + col] = peak * k.J[f][18 + cc];
                 for (int i = 0; i < 3; i++) {
                     Jx[(r_ct + 3 * f + i) * nx + WQ + col] = c * (k.Jd[f][9 * i + cc] + (i == 2 ? pg * k.J[f][18 + cc] : 0));
@@ -1099,9 +1103,10 @@ int oracle_num_threads(void) {
 
 /* shift a warm start left by `shift` stages (solver.py:304-322): states 1..N-shift
  * take the old states shift+1..N, inputs 0..N-shift-1 take the old shift..N-1,
- * the newly exposed input tail is zero-filled (solver.py:320); the state tail keeps
- * its previous values (repeat_last=False leaves them untouched, solver.py:328). */
-void oracle_shift_warm_start(int nx, int nu, int N, int B, int shift, real *X, real *U) {
+ * the newly exposed tail of the contact forces is zero-filled (solver.py:320); the state tail and the
+ * tail of the first nu_keep inputs (the whole-body model's accelerations: solver.py:316 writes
+ * [:, :n_warm_start] only) keep their previous values (repeat_last=False, solver.py:328). */
+void oracle_shift_warm_start(int nx, int nu, int nu_keep, int N, int B, int shift, real *X, real *U) {
     if (shift <= 0) return;
     if (shift > N) shift = N;
     const int nw = N - shift;
@@ -1109,7 +1114,8 @@ void oracle_shift_warm_start(int nx, int nu, int N, int B, int shift, real *X, r
         real *x = X + (size_t)b * (N + 1) * nx, *u = U + (size_t)b * N * nu;
         memmove(x + nx, x + (size_t)(shift + 1) * nx, sizeof(real) * nw * nx);
         memmove(u, u + (size_t)shift * nu, sizeof(real) * nw * nu);
-        memset(u + (size_t)nw * nu, 0, sizeof(real) * shift * nu);
+        for (int k = nw; k < N; k++)
+            for (int i = nu_keep; i < nu; i++) u[(size_t)k * nu + i] = 0;
     }
 }
 

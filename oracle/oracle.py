@@ -165,11 +165,15 @@ class Oracle:
         self.lib.oracle_wb_feet(self._p(self._mp(mp)), self._p(x), self._p(pos), self._p(vel))
         return pos, vel
 
-    def shift_warm_start(self, X, U, shift):
+    def shift_warm_start(self, X, U, shift, nu_keep=None):
+        """nu_keep: leading inputs whose exposed tail keeps the previous values -- the whole-body model's 18
+        accelerations (solver.py:316-322 zeroes the forces only); default by the input width"""
         B, N1, nx = X.shape
         nu = U.shape[2]
+        if nu_keep is None:
+            nu_keep = 18 if nu == 30 else 0
         X, U = self._a(X).copy(), self._a(U).copy()
-        self.lib.oracle_shift_warm_start(nx, nu, N1 - 1, B, int(shift), self._p(X), self._p(U))
+        self.lib.oracle_shift_warm_start(nx, nu, int(nu_keep), N1 - 1, B, int(shift), self._p(X), self._p(U))
         return X, U
 
     def tracking_error(self, S, Snom):

@@ -71,12 +71,48 @@ def test_optimize_call_sequence_fills_the_views_as_the_reference_does():
     assert np.allclose(p["X"][0, 0], p["x0"][0]) and (p["X"][0, 1:] == 0).all()   # first call: no warm start (solver.py:386-388)
     assert np.allclose(p["yref"][0, :, :12], base_ref) and np.allclose(p["yref"][0, :, 48:52], 0.05)
     n_st = p["params"][0, :N, :4].sum(1)
-    assert np.allclose(p["yref"][0, :, 54::3].sum(1), 15.0 * 9.81 * (n_st > 0))    # gravity share [decl]
+    assert (p["yref"][0, :, 52:64] == 0).all()                                    # forces regularised to zero, as solver.py:128-130
+    assert (p["yref"][0, :, 64:] == 0).all() and (p["yref_e"][0, 40:] == 0).all()  # contact, consistency; no foot-placement plan
     W, We = wl.wholebody_weights(mpc.config_cost)
-    assert np.array_equal(s._W, W) and np.array_equal(s._W_e, We)
+    assert np.array_equal(s._W, W) and np.array_equal(s._W_e, We) and (W[82:] == 0).all()
+    # the workload's choice, opt-in: forces regularised to the stance feet's share of the weight [decl]
+    g = LocomotionMPC(print_info=False, force_reference="gravity_share")
+    g.set_command(np.array([0.3, 0., 0.]), 0.)
+    g.solver.init(*g.solver_inputs(q, v))
+    pg = g.solver.pack_problem()
+    assert np.allclose(pg["yref"][0, :, 54:64:3].sum(1), 15.0 * 9.81 * (n_st > 0))
+    for k in ("x0", "yref_e", "params", "X", "U"):
+        assert np.array_equal(pg[k], p[k])
 
 
-def test_first_solve_policy_and_warm_start_shift():
+def test_unsupported_settings_are_announced_not_dropped_silently():
+    """torque limits (on by default in the reference, config_abstract.py:68) and the hard patch constraint of the
+    contact-restricted mode are not part of the solved model: a warning says so once, strict=True refuses"""
+    cfg = get_quadruped_config_for_test()
+    with pytest.warns(UserWarning, match="torque_limit"):
+        s = QuadrupedAcadosSolver("", list(wl.FEET), cfg[1], cfg[2])
+    assert s.unsupported == ["torque_limit"]
+    with pytest.warns(UserWarning, match="patch constraint"):
+        s.set_contact_restriction(True)
+    assert s.unsupported == ["torque_limit", "patch_restriction"]
+    W = s._W
+    assert (W[82:] == cfg[2].W_foot_displacement[0]).all() and (s._W_e[58:] == cfg[2].W_foot_displacement[0]).all()
+    with pytest.raises(NotImplementedError):
+        QuadrupedAcadosSolver("", list(wl.FEET), cfg[1], cfg[2], strict=True)
+    cfg[1].torque_limit = False
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        quiet = QuadrupedAcadosSolver("", list(wl.FEET), cfg[1], cfg[2], strict=True)
+    assert quiet.unsupported == []
+
+
+def get_quadruped_config_for_test():
+    from iterative_learning_nmpc_amd.config import get_quadruped_config
+    return get_quadruped_config("trot", "go2")
+
+
+def test_first_solve_policy_and_warm_start_shift(oracle64):
     mpc = LocomotionMPC(print_info=False)
     s, d, N = mpc.solver, mpc.solver.dyn, mpc.config_opt.n_nodes
     mpc.set_convergence_on_first_iter()
@@ -99,6 +135,9 @@ def test_first_solve_policy_and_warm_start_shift():
     assert (p["U"][0, N - 2:, 18:] == 0).all()                                # force tail zeroed (solver.py:320)
     assert np.array_equal(p["U"][0, N - 2:, :18], U[0, N - 2:, :18])          # acceleration tail untouched
     assert s.last_node == 2
+    # the oracle's shift (and with it the C-ABI's, which the -m gpu tests hold bit-equal to the oracle's) is this shift
+    Xs, Us = oracle64.shift_warm_start(X, U, 2)
+    assert np.array_equal(p["X"][0, 1:], Xs[0, 1:]) and np.array_equal(p["U"], Us)
 
 
 def test_batched_views_and_raibert_planner():
@@ -108,7 +147,7 @@ def test_batched_views_and_raibert_planner():
     mpc.set_command(np.array([0.2, 0.1, 0.]), 0.1)
     mpc.solver.init(*mpc.solver_inputs(q, v))
     p = mpc.solver.pack_problem()
-    assert p["x0"].shape == (B, 42) and p["params"].shape == (B, 31, 20) and p["yref"].shape == (B, 30, 82)
+    assert p["x0"].shape == (B, 42) and p["params"].shape == (B, 31, 20) and p["yref"].shape == (B, 30, 90)
     single = LocomotionMPC(print_info=False, n_nodes=30)
     single.set_command(np.array([0.2, 0.1, 0.]), 0.1)
     single.solver.init(*single.solver_inputs(q[1], v[1]))
@@ -125,6 +164,13 @@ def test_batched_views_and_raibert_planner():
     f0 = r.solver.dyn.feet[0]
     assert r.solver.restrict_cnt and (r.solver.params[f0.range_radius.name] == r.config_cost.cnt_radius).all()
     assert np.allclose(r.solver.cost_ref[f0.pos_cost.name], args[8][0, 1:, :].T)
+    # ... and the plan reaches the solved problem: foot-placement references (x, y of node k + 1 at stage k) and weights
+    pr = r.solver.pack_problem()
+    Nr = r.config_opt.n_nodes
+    for i in range(4):
+        assert np.array_equal(pr["yref"][0, :, 82 + 2 * i:84 + 2 * i], args[8][i, 1:, :2])
+        assert np.array_equal(pr["yref_e"][0, 58 + 2 * i:60 + 2 * i], args[8][i, Nr, :2])
+    assert (r.solver._W[82:] == r.config_cost.W_foot_displacement[0]).all()
 
 
 def test_solve_without_a_device_fails_loudly():

@@ -116,9 +116,33 @@ def test_wholebody_odd_batches_and_horizons(dev, oracle64, B, N):
     w = wl.wholebody_trot(B=B, N=N, seed=7)
     s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2)
     X, U, st, _ = _gpu_solve(s, w)
-    Xo, Uo, sto, _ = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2)
+    Xo, Uo, sto, statso = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2)
     assert np.array_equal(st, sto)
     assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))
+    # cost at the last linearisation, every node counted (N = 64: node 64 has no lane of its own), and the iteration count
+    assert np.allclose(stats[:, 0], statso[:, 0], rtol=2e-5) and np.array_equal(stats[:, 3], statso[:, 3])
+
+
+def test_wholebody_foot_placement_cost(dev, oracle64):
+    """the reference's contact-restricted cost (pos_cost with W_foot_displacement = 1e3, solver.py:128-137,272-273) in the
+    solved model: eight more rows of the dense residual Jacobian, inside the two K tiles the contraction runs anyway.
+    Parity with the oracle; and a handle whose weights go back to zero solves exactly what a fresh handle solves (the rows
+    of the Jacobian image are exact zeros again)."""
+    B = 32
+    w = wl.wholebody_trot(B=B, N=30, seed=8, foot_placement=1.0e3)
+    s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=3)
+    X, U, st, stats = _gpu_solve(s, w)
+    Xo, Uo, sto, statso = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=3)
+    assert np.array_equal(st, sto)
+    assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))
+    assert np.allclose(stats[:, 0], statso[:, 0], rtol=2e-5)
+    w0 = wl.wholebody_trot(B=B, N=30, seed=8)
+    assert rel(X, _oracle_solve(oracle64, w0, n_ipm=6, max_sqp_iter=3)[0]) > 1e-3          # the cost term does something
+    s.set_cost_weights(w0.W, w0.W_e, w0.meta["reg"], w0.meta["reg_e"])
+    X0, U0, _, _ = _gpu_solve(s, w0)
+    fresh = _solver(w0, B, dev, n_ipm=6, max_sqp_iter=3)
+    Xf, Uf, _, _ = _gpu_solve(fresh, w0)
+    assert np.array_equal(X0, Xf) and np.array_equal(U0, Uf)
 
 
 def test_wholebody_stage_constant_reference(dev, oracle64):
@@ -151,6 +175,43 @@ def test_wholebody_warm_start_shift_folded(dev, oracle64):
     Xs, Us = oracle64.shift_warm_start(Xo1, Uo1, 30)
     Xo3, Uo3, _, _ = _oracle_solve(oracle64, w, X=Xs, U=Us)
     assert rel(X3, Xo3) < 1e-5 and rel(U3, Uo3) < 1e-5
+
+
+def test_wholebody_shift_zeroes_forces_and_keeps_accelerations(dev, oracle64):
+    """solver.py:316-322: the warm-start shift moves a[:, :n_warm_start] and f[:, :n_warm_start] and zeroes f[:, n_warm_start:] --
+    the acceleration tail keeps the previous solution's values.  The device shift (nmpc_shift_warm_start) and the oracle's agree
+    bit for bit (the facade's `warm_start_solver` on its views against the oracle: tests/test_facade.py)."""
+    B, N, shift = 3, 30, 4
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((B, N + 1, 42)).astype(np.float32)
+    U = rng.standard_normal((B, N, 30)).astype(np.float32)
+    w = wl.wholebody_trot(B=B, N=N, seed=0)
+    s = _solver(w, B, dev)
+    Xd, Ud = s.to_device(X), s.to_device(U)
+    s.warm_start_solver(Xd, Ud, shift)
+    torch.cuda.synchronize()
+    Xo, Uo = oracle64.shift_warm_start(X, U, shift)
+    assert np.array_equal(Xd.cpu().numpy(), Xo.astype(np.float32)) and np.array_equal(Ud.cpu().numpy(), Uo.astype(np.float32))
+    assert np.array_equal(Uo[:, N - shift:, :18], U[:, N - shift:, :18]) and (Uo[:, N - shift:, 18:] == 0).all()
+    assert np.array_equal(Uo[:, :N - shift], U[:, shift:])
+
+
+def test_wholebody_solves_are_bit_reproducible(dev):
+    """Two solves of the same inputs give the same bits, run to run and across the contact patterns of a batch -- the guard
+    for the two scheduling hazards DESIGN.md 5b records (an inline-asm v_readlane behind a VALU write, MFMA results joined
+    behind a uniform branch), which showed up as a run-to-run varying 5e-5 error."""
+    B = 256
+    w = wl.wholebody_trot(B=B, N=30, seed=4)
+    s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2)
+    ref = None
+    for _ in range(3):
+        X, U, st, stats = _gpu_solve(s, w)
+        if ref is None:
+            ref = (X, U, st, stats)
+        assert np.array_equal(X, ref[0]) and np.array_equal(U, ref[1]) and np.array_equal(st, ref[2]) and np.array_equal(stats, ref[3])
+    X, U, _, _ = _gpu_solve(s, w, shift=1, X=ref[0], U=ref[1])
+    X2, U2, _, _ = _gpu_solve(s, w, shift=1, X=ref[0], U=ref[1])
+    assert np.array_equal(X, X2) and np.array_equal(U, U2)
 
 
 def test_wholebody_early_exit_and_status(dev, oracle64):
@@ -210,13 +271,16 @@ def test_wholebody_full_size_properties(dev, oracle64):
     assert rel(X[:n], Xo) < 1e-5 and rel(U[:n], Uo) < 1e-5
 
 
-@pytest.mark.parametrize("precision,sqp,lo,hi", [(1, 1, 1e-3, 1e-2), (1, 15, 8e-4, 8e-3), (2, 1, 4e-5, 5e-4), (2, 15, 0.0, 1e-5)])
+@pytest.mark.parametrize("precision,sqp,lo,hi", [(3, 1, 0.0, 1e-5), (3, 15, 0.0, 1e-5),
+                                                 (1, 1, 1e-3, 1e-2), (1, 15, 8e-4, 8e-3), (2, 1, 4e-5, 5e-4), (2, 15, 0.0, 1e-5)])
 def test_wholebody_mixed_precision(dev, oracle64, precision, sqp, lo, hi):
-    """BASELINE configs[4] on the model that has a dense Gauss-Newton contraction: the scaled residual Jacobian rounded
-    to bf16 (precision 1) or split into bf16 head + tail (precision 2), Q~ = Js'Js on the bf16 matrix pipe with fp32
-    accumulation, fp32 Riccati.  Documented outcome (DESIGN.md 7, B = 64): plain bf16 sits at 3.5e-3 after one SQP
-    iteration and 2.4e-3 converged -- 8 bits of mantissa in the Hessian; split bf16 at 1.4e-4 after one iteration and
-    3.7e-6 converged, i.e. inside the 1e-5 bar once the iteration has contracted the Hessian error."""
+    """BASELINE configs[4] on the model that has a dense Gauss-Newton contraction: the scaled residual Jacobian in bf16,
+    Q~ = Js'Js on the bf16 matrix pipe (v_mfma_f32_16x16x16_bf16) with fp32 accumulation, fp32 Riccati.
+    Precision 3, the shipped recommendation: Js = hi + mid + lo (three bf16 numbers carry the 24 bits of the fp32
+    value), six products -- INSIDE the 1e-5 bar at the steady-state policy the bench runs (1 SQP x 6 IPM) and at the
+    first-solve policy.  Documented negatives kept as bands (DESIGN.md 7, B = 64): plain bf16 (precision 1) sits at 3.5e-3
+    after one SQP iteration and 2.4e-3 converged -- 8 bits of mantissa in the Hessian; two-way split bf16 (precision 2) at
+    1.4e-4 after one iteration and 3.7e-6 converged."""
     from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
     B = 64
     w = wl.wholebody_trot(B=B, N=30, seed=0)
@@ -238,9 +302,11 @@ def test_wholebody_api_limits(dev):
     with pytest.raises(NmpcError):
         BatchedNmpcSolver(wl.MODEL_WHOLEBODY, 65, 4, dev)            # lane = stage phases: N <= 64
     with pytest.raises(NmpcError):
-        BatchedNmpcSolver(wl.MODEL_WHOLEBODY, 30, 4, dev, precision=3)
+        BatchedNmpcSolver(wl.MODEL_WHOLEBODY, 30, 4, dev, precision=4)
     with pytest.raises(NmpcError):
         BatchedNmpcSolver(wl.MODEL_CENTROIDAL, 50, 4, dev, precision=2)      # split bf16 exists for the whole-body contraction only
+    with pytest.raises(NmpcError):
+        BatchedNmpcSolver(wl.MODEL_CENTROIDAL, 50, 4, dev, precision=3)
     w = wl.wholebody_trot(B=2, N=30, seed=0)
     s = _solver(w, 2, dev)
     s.set_line_search(True)
@@ -262,7 +328,7 @@ def test_facade_optimize_is_the_oracle_solution_of_its_packed_problem(dev, oracl
     solve with the reference's first-solve policy (15 SQP, tolerances / 10: mpc.py:464-473), then a warm-started
     steady-state solve one node later -- both equal the oracle's solution of the arrays `update_solver` packed."""
     from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
-    mpc = LocomotionMPC(print_info=False, n_nodes=30, device=dev)
+    mpc = LocomotionMPC(print_info=False, n_nodes=30, device=dev, force_reference="gravity_share")
     mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
     q, v = _robot_state(0)
     s = mpc.solver
@@ -299,7 +365,7 @@ def test_facade_open_loop_keeps_the_robot_up(dev):
     """0.2 s of the reference's simulator-free rollout (mpc.py:416-462): six replans, plan followed at 1 kHz"""
     from iterative_learning_nmpc_amd import wholebody as wbk
     from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
-    mpc = LocomotionMPC(print_info=False, device=dev)
+    mpc = LocomotionMPC(print_info=False, device=dev, force_reference="gravity_share")   # [decl] the facade's default is the reference's zero
     mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
     q0 = np.zeros(18); q0[2] = 0.30; q0[6:] = wbk.Q_HOME
     traj = mpc.open_loop(q0, np.zeros(18), 0.2)

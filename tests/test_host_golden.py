@@ -131,3 +131,22 @@ def test_euler_rate_maps(golden_dir):
         assert np.allclose(refs.euler_derivative_to_local_angular(ypr, w), b, rtol=0, atol=1e-14)
         # the two maps are inverses of each other
         assert np.allclose(refs.euler_derivative_to_local_angular(ypr, a), w, atol=1e-12)
+
+
+def test_base_ref_cnt_restricted(golden_dir):
+    """`LocomotionMPC.compute_base_ref_cnt_restricted` (mpc.py:274-315): base references from a contact-location plan --
+    Raibert plans of the reference's own planner, plans with unplanned (all-zero) stretches, fully planned, nothing
+    planned.  Bit for bit the reference's outputs, and the facade's method is this function."""
+    from iterative_learning_nmpc_amd.references import base_ref_cnt_restricted
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    g = np.load(os.path.join(golden_dir, "cnt_restricted.npz"))
+    n = g["heights"].shape[0]
+    assert n >= 10
+    for i in range(n):
+        h, off = g["heights"][i]
+        ref, ref_e = base_ref_cnt_restricted(g[f"loc{i}"], h, off)
+        assert np.array_equal(ref, g[f"ref{i}"][0]) and np.array_equal(ref_e, g[f"ref{i}"][1]), i
+    mpc = LocomotionMPC(print_info=False)
+    ref, ref_e = mpc.compute_base_ref_cnt_restricted(np.zeros(18), g["loc0"])
+    want = base_ref_cnt_restricted(g["loc0"], mpc.config_gait.nom_height, mpc.height_offset)
+    assert np.array_equal(ref, want[0]) and np.array_equal(ref_e, want[1])

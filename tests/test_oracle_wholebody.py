@@ -52,7 +52,7 @@ def test_residual_jacobian_matches_finite_differences(oracle64, terminal):
         x, u, p = _state(np.random.default_rng(10 + seed))
         uu = None if terminal else u
         res, J = o.wb_residuals(mp, x, uu, p)
-        assert res.shape == ((58,) if terminal else (82,))
+        assert res.shape == ((66,) if terminal else (90,))
         assert np.abs(J - _fd(lambda z: o.wb_residuals(mp, z, uu, p, jac=False), x)).max() < 1e-6   # entries up to p_gain = 50
 
 
@@ -200,3 +200,34 @@ def test_converged_wholebody_solution_equals_slsqp_optimum_over_ten_and_twenty_n
     assert binding >= 4, binding
     assert np.abs(U[0] - g["Us"]).max() < tol_u * np.abs(g["Us"]).max() and np.abs(X[0] - g["Xs"]).max() < tol_x, \
         (np.abs(U[0] - g["Us"]).max() / np.abs(g["Us"]).max(), np.abs(X[0] - g["Xs"]).max())
+
+
+def test_foot_placement_rows_are_the_feet_against_the_plan(oracle64):
+    """pos_cost (solver.py:128-137,272-273): residual rows 82..89 (terminal 58..65) are the world x, y of the four feet minus
+    the planned location; their Jacobian is covered by test_residual_jacobian_matches_finite_differences; with the weight of
+    the reference's contact-restricted mode the converged solution puts the feet closer to the plan than without it"""
+    o = oracle64
+    mp = o.mp(dt=1 / 30)
+    x, u, p = _state(np.random.default_rng(3))
+    yref, yref_e = np.zeros(90), np.zeros(66)
+    plan = np.random.default_rng(4).normal(0, 0.3, 8)
+    yref[82:], yref_e[58:] = plan, plan
+    feet = o.wb_feet(mp, x)[0][:, :2].ravel()
+    r = o.wb_residuals(mp, x, u, p, yref=yref, jac=False)
+    re = o.wb_residuals(mp, x, None, p, yref=yref_e, jac=False)
+    assert np.allclose(r[82:], feet - plan, atol=1e-14) and np.allclose(re[58:], feet - plan, atol=1e-14)
+    dist = {}
+    for wgt in (0.0, 1.0e3):                     # W_foot_displacement of the reference (mpc_cost.py:63)
+        w = wl.wholebody_trot(B=2, N=12, seed=6, foot_placement=wgt)
+        if wgt == 0.0:
+            plan_w = wl.wholebody_trot(B=2, N=12, seed=6, foot_placement=1.0)
+            ref = plan_w.yref[:, :, 82:90]
+        X, U, st, _ = o.solve_batch(2, w.N, w.mp, o.opt(max_sqp_iter=10, n_ipm=6, yref_per_stage=1, reg=w.meta["reg"], reg_e=w.meta["reg_e"]),
+                                    w.W, w.W_e, w.x0, w.yref, w.yref_e, w.params, w.X, w.U)
+        assert (st != 1).all() and (st != 4).all()
+        d = 0.0
+        for b in range(2):
+            for k in range(1, w.N + 1):
+                d += np.sum((o.wb_feet(w.mp, X[b, k])[0][:, :2].ravel() - ref[b, k - 1]) ** 2)
+        dist[wgt] = d
+    assert dist[1.0e3] < 0.5 * dist[0.0], dist

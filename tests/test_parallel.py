@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors, learning_update, shard_bounds
+from iterative_learning_nmpc_amd.parallel import all_gather_tracking_errors, all_gather_validity, learning_update, shard_bounds
 
 
 def test_shard_bounds_partition_everything():
@@ -40,6 +40,12 @@ def _worker(rank, world, port, total, K, out_dir):
         ood, w = learning_update(gathered)
         ok = torch.equal(gathered, full) and torch.equal(w, torch.where(full > 4.0, 5.0, 1.0)) \
             and torch.equal(ood, full > 4.0)
+        # validity flags ride the same exchange: every rank masks the same rollouts (every third one invalid here)
+        valid_full = (torch.arange(total) % 3) != 1
+        valid = all_gather_validity(valid_full[lo:hi].clone(), total)
+        ood_v, w_v = learning_update(gathered, valid=valid)
+        ok = ok and torch.equal(valid, valid_full) and bool((w_v[~valid_full] == 0).all()) and not bool(ood_v[~valid_full].any()) \
+            and torch.equal(w_v[valid_full], w[valid_full])
         # every rank holds the same result
         digest = torch.tensor([float(w.sum())])
         lst = [torch.zeros(1) for _ in range(world)]
@@ -67,3 +73,16 @@ def test_ood_threshold_mapping():
     from iterative_learning_nmpc_amd.parallel import ood_threshold
     assert ood_threshold(44) == 4.0
     assert abs(ood_threshold(19) - 4.0 * (18 / 43) ** 0.5) < 1e-15 and abs(ood_threshold(19) - 2.588) < 1e-3
+
+
+def test_invalid_and_nan_rollouts_get_no_sampling_weight():
+    """A rollout that was terminated and not redone, or whose error is not finite (a failed solve), is not data: weight 0 and
+    never out-of-distribution -- compared with the threshold a NaN would silently read as in-distribution, weight 1
+    (the reference deletes such a rollout's file, DAgger/utils/RolloutMPC.py:432-435)."""
+    err = torch.tensor([[0.5, 5.0, 1.0], [float("nan"), 6.0, 0.1], [4.5, 0.2, float("inf")], [9.0, 9.0, 9.0]])
+    ood, w = learning_update(err, threshold=4.0)
+    assert torch.equal(w, torch.tensor([[1.0, 5.0, 1.0], [0.0, 5.0, 1.0], [5.0, 1.0, 0.0], [5.0, 5.0, 5.0]]))
+    assert torch.equal(ood, torch.tensor([[False, True, False], [False, True, False], [True, False, False], [True, True, True]]))
+    valid = torch.tensor([True, True, True, False])                 # rollout 3: unsafe / terminated, not redone
+    ood, w = learning_update(err, threshold=4.0, valid=valid)
+    assert (w[3] == 0).all() and not ood[3].any() and w[1, 0] == 0 and torch.equal(w[0], torch.tensor([1.0, 5.0, 1.0]))
