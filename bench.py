@@ -322,7 +322,41 @@ def wholebody_legs(a, dev, want_cpu):
                 leg["cpu_baseline"] = cb
         out[key] = leg
         del su
+    out["wholebody"]["single_problem_latency"] = single_solve_latency(dev)
     return out
+
+
+def single_solve_latency(dev):
+    """B = 1 through the reference-shaped facade, the reference's own horizon (N = 25, mpc_opt.py:11-13): wall time of
+    `LocomotionMPC.optimize(q, v)` -- host assembly of the views, six uploads, the solve, four downloads, one
+    synchronisation -- for the first solve (15 SQP iterations) and for steady-state replans, next to the reference's budget
+    of 40 ms per solve (replanning at 25 Hz, mpc_opt.py:15)."""
+    import warnings
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mpc = LocomotionMPC(print_info=False, device=dev, force_reference="gravity_share")
+    mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+    q = np.zeros(18); q[2] = 0.30; q[6:] = wbk.Q_HOME
+    v = np.zeros(18)
+    mpc.solver._device_solver()                      # handle creation is set-up, not a solve
+    mpc.set_convergence_on_first_iter()
+    t0 = time.perf_counter()
+    q_sol, v_sol, *_ = mpc.optimize(q, v)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    mpc.first_solve = False
+    mpc.sim_step, mpc.current_opt_node = mpc.replanning_steps, 1
+    mpc.set_convergence_on_first_iter()
+    times = []
+    for i in range(30):
+        t0 = time.perf_counter()
+        q_sol, v_sol, *_ = mpc.optimize(q_sol[1].copy(), v_sol[1].copy())
+        times.append((time.perf_counter() - t0) * 1e3)
+        mpc.current_opt_node += 1
+    times = np.array(times[5:])
+    return {"horizon": mpc.config_opt.n_nodes, "first_solve_ms": first_ms, "steady_ms_mean": float(times.mean()), "steady_ms_max": float(times.max()),
+            "reference_budget_ms": 40.0, "path": "LocomotionMPC.optimize -> QuadrupedAcadosSolver.init / solve (views -> pinned buffers -> device -> views)"}
 
 
 def rollout_leg(B, steps, warmup, world, rank, dev, dist, max_attempts=8):

@@ -239,6 +239,47 @@ int nmpc_rollout_batch(void *handle, int B, const nmpc_rollout_cfg *cfg, const s
                        const float *push_force, const float *phase, float *X, float *U, float *S,
                        int *status, int *failed, void *stream);
 
+#define NMPC_ROLLOUT_FLAG_JOINT_LIMIT   64   /* whole-body rollouts: a joint outside hip +-70, thigh [25, 115], knee [-155, -60] deg
+                                             * (check_unsafe_state_v2, Rollout_combined_controller.py:386-409) */
+
+/* Device-resident rollouts of the WHOLE-BODY model: the reference's own problem through its own loop,
+ * LocomotionMPC.open_loop (mpc_controller/mpc.py:416-462), for B rollouts from ONE host call.  Per replanning step:
+ * what `optimize` hands to `solver.init` (mpc.py:325-366; solver.py:153-252,355-394 -- contact / peak windows, base
+ * references, joint / swing / force references, x0 with its momentum slots, plane points with the stance feet anchored
+ * by forward kinematics), the solve with the warm-start shift folded in (first one: 15 SQP iterations from the zero
+ * guess, solver.py:386-388), then the plan up-sampled by cubic Hermite segments (mpc.py:388-414) and followed as the
+ * plant for `replanning_steps` simulation steps.  All rollouts share the gait clock. */
+typedef struct {
+    int n_replans;            /* replanning steps to run                                                   */
+    int replanning_steps;     /* simulation steps between two replans (mpc.py:113)                         */
+    int nodes_per_cycle;      /* columns of the contact / peak tables                                      */
+    int first_solve;          /* 1: the first replan is the reference's first solve                        */
+    int last_node;            /* first_solve = 0: node of the previous solve (warm-start shift = node - last) */
+    int max_sqp_first;        /* 15                                                                        */
+    float nlp_tol_first;      /* nlp_tol / 10                                                              */
+    float nlp_tol;
+    double sim_dt, time_horizon, nom_height, height_offset;
+    float step_height;        /* swing-height reference (mpc_gait.py:15-21)                                */
+    float push_start, push_duration;
+    int record_sim_steps;     /* 0: one row per replan (the state it starts from); 1: one per simulation step */
+    int force_reference_gravity;   /* 0: forces regularised to zero (solver.py:128-130); 1: to the stance feet's weight share [decl] */
+    float nominal_period;     /* gait period, for the recorded phase                                       */
+    int terminate_mask;       /* as nmpc_rollout_cfg                                                       */
+    float collision_height;
+} nmpc_wb_rollout_cfg;
+/* gait, peaks: dev int8 [4][nodes_per_cycle] (contact_planner.py:45-149); nodes: HOST int[n_replans], the optimisation node
+ * of each replan (the reference advances it on a float clock, mpc.py:171-186: the host mirror reproduces that clock);
+ * q, v: dev [B][18] in initial / out final plant state, Euler layout (q = r, yaw, pitch, roll, joints; v = qdot);
+ * v_des, w_des, ref_state as nmpc_rollout_batch; joint_ref: dev [12]; push_force: dev [B][3] or NULL;
+ * X [B][N+1][42], U [B][N][30]: dev trajectories in/out; S: dev [B][n_rows][44], rows in the reference's layout
+ * [phase, v_mj(18), q_mj[2:](17) = z, quaternion wxyz, joints, base_wrt_feet(8)] (DAgger/utils/RolloutMPC.py:221,
+ * dynamics.py:75-98); failed: dev int [B] as nmpc_rollout_batch, plus NMPC_ROLLOUT_FLAG_JOINT_LIMIT.
+ * Needs a handle of NMPC_MODEL_WHOLEBODY with line_search = 0; B <= B_max. */
+int nmpc_wb_rollout_batch(void *handle, int B, const nmpc_wb_rollout_cfg *cfg, const signed char *gait,
+                          const signed char *peaks, const int *nodes, float *q, float *v, const double *v_des,
+                          const double *w_des, double *ref_state, const float *joint_ref, const float *push_force,
+                          float *X, float *U, float *S, int *status, int *failed, void *stream);
+
 /* Problems to leave out of the following *_batch solves of this handle: flags dev int[B_max] (or NULL: none); a problem
  * with flags[b] & mask != 0 is skipped by every kernel -- its X, U, status, stats stay as they are and it costs no
  * time.  The flags are read when the kernels run (stream order), so the caller may update them between calls without

@@ -36,6 +36,7 @@ SIGNATURES = {
     "nmpc_tracking_error": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p]),
     "nmpc_rollout_batch": (c_int, [c_void_p, c_int, c_void_p] + [c_void_p] * 14),
+    "nmpc_wb_rollout_batch": (c_int, [c_void_p, c_int, c_void_p] + [c_void_p] * 16),
     # include/nmpc_policy.h
     "nmpc_policy_create": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     "nmpc_policy_destroy": (None, [c_void_p]),
@@ -91,6 +92,15 @@ class NmpcRolloutCfg(ctypes.Structure):
                 ("height_offset", ctypes.c_double), ("push_start", c_float), ("push_duration", c_float),
                 ("footsteps", c_int), ("record_sim_steps", c_int), ("hip_offset", c_float * 8),
                 ("stance_ratio", c_float * 4), ("nominal_period", c_float), ("foot_size", c_float),
+                ("terminate_mask", c_int), ("collision_height", c_float)]
+
+
+class NmpcWbRolloutCfg(ctypes.Structure):
+    _fields_ = [("n_replans", c_int), ("replanning_steps", c_int), ("nodes_per_cycle", c_int), ("first_solve", c_int),
+                ("last_node", c_int), ("max_sqp_first", c_int), ("nlp_tol_first", c_float), ("nlp_tol", c_float),
+                ("sim_dt", ctypes.c_double), ("time_horizon", ctypes.c_double), ("nom_height", ctypes.c_double),
+                ("height_offset", ctypes.c_double), ("step_height", c_float), ("push_start", c_float), ("push_duration", c_float),
+                ("record_sim_steps", c_int), ("force_reference_gravity", c_int), ("nominal_period", c_float),
                 ("terminate_mask", c_int), ("collision_height", c_float)]
 
 

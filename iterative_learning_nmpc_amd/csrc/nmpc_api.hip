@@ -13,6 +13,7 @@
 #include "nmpc_wb.hip"
 #include "nmpc_aux.hip.inc"
 #include "nmpc_rollout.hip.inc"
+#include "nmpc_wb_rollout.hip.inc"
 
 namespace {
 
@@ -264,7 +265,7 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     }
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
     if (e == hipSuccess) {
-        const size_t per = (size_t)dims->N * h->ny + h->nye + (size_t)(dims->N + 1) * (np > 0 ? np : 1);
+        const size_t per = (size_t)dims->N * h->ny + h->nye + (size_t)(dims->N + 1) * (np > 0 ? np : 1) + nx;   // yref, yref_e, params, x0 of the rollouts
         e = hipMalloc(reinterpret_cast<void**>(&h->roll), (size_t)dims->B_max * per * sizeof(float));
     }
     if (e != hipSuccess) {
@@ -546,6 +547,79 @@ int nmpc_rollout_batch(void* handle, int B, const nmpc_rollout_cfg* cfg, const s
         const int rc = launch_solve<nmpc::Centroidal>(h, a, st);
         if (rc) return rc;
         hipLaunchKernelGGL(nmpc::nmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, r);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_wb_rollout_batch(void* handle, int B, const nmpc_wb_rollout_cfg* cfg, const signed char* gait, const signed char* peaks,
+                          const int* nodes, float* q, float* v, const double* v_des, const double* w_des, double* ref_state,
+                          const float* joint_ref, const float* push_force, float* X, float* U, float* S, int* status,
+                          int* failed, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return NMPC_E_ARG;
+    if (B == 0) return NMPC_OK;
+    if (!cfg || !gait || !peaks || !nodes || !q || !v || !v_des || !w_des || !ref_state || !joint_ref || !X || !U || !S || !status || !failed)
+        return fail(h, NMPC_E_ARG, "null argument");
+    if (h->dims.model_id != NMPC_MODEL_WHOLEBODY) return fail(h, NMPC_E_ARG, "nmpc_wb_rollout_batch needs the whole-body model");
+    if (B < 0 || B > h->dims.B_max) return fail(h, NMPC_E_ARG, "B exceeds B_max");
+    if (cfg->n_replans < 1 || cfg->replanning_steps < 1 || cfg->nodes_per_cycle < 1 || !(cfg->sim_dt > 0) || !(cfg->time_horizon > 0))
+        return fail(h, NMPC_E_ARG, "rollout configuration out of range");
+    if (!h->mp_set || !h->w_set) return fail(h, NMPC_E_STATE, "model parameters / weights not set");
+    if (h->line_search) return fail(h, NMPC_E_ARG, "the whole-body model takes full steps (line_search = 0)");
+    const int N = h->dims.N;
+    if (cfg->replanning_steps * cfg->sim_dt > cfg->time_horizon) return fail(h, NMPC_E_ARG, "replanning interval longer than the horizon");
+    for (int i = 0; i < cfg->n_replans; ++i)
+        if (nodes[i] < 0 || (i > 0 && nodes[i] < nodes[i - 1])) return fail(h, NMPC_E_ARG, "nodes must be non-negative and non-decreasing");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    nmpc::DeviceGuard guard(h->device);
+    HIP_TRY(h, guard.err);
+    if (h->ws_dirty) {
+        HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
+        h->ws_dirty = false;
+    }
+    float* yref = h->roll;
+    float* yref_e = yref + (size_t)h->dims.B_max * N * h->ny;
+    float* params = yref_e + (size_t)h->dims.B_max * h->nye;
+    float* x0 = params + (size_t)h->dims.B_max * (N + 1) * h->np;
+    nmpc::wb::WbRolloutArgs r{};
+    r.B = B; r.N = N; r.npc = cfg->nodes_per_cycle; r.replanning_steps = cfg->replanning_steps; r.n_replans = cfg->n_replans;
+    r.record_sim_steps = cfg->record_sim_steps ? 1 : 0; r.force_gravity = cfg->force_reference_gravity ? 1 : 0;
+    r.sim_dt = cfg->sim_dt; r.t_horizon = cfg->time_horizon; r.nom_height = cfg->nom_height; r.height_offset = cfg->height_offset;
+    r.dt_nodes = cfg->time_horizon / N;
+    r.step_height = cfg->step_height; r.nominal_period = cfg->nominal_period; r.collision_height = cfg->collision_height;
+    r.term_mask = cfg->terminate_mask & NMPC_ROLLOUT_FLAG_MASK;
+    r.mp = h->mp;
+    r.gait = gait; r.peaks = peaks; r.q = q; r.v = v; r.v_des = v_des; r.w_des = w_des; r.ref_state = ref_state;
+    r.joint_ref = joint_ref; r.push_force = push_force;
+    r.x0 = x0; r.yref = yref; r.yref_e = yref_e; r.params = params; r.X = X; r.U = U; r.S = S; r.status = status; r.failed = failed;
+    const int rows_per_replan = r.record_sim_steps ? cfg->replanning_steps : 1;
+    r.n_rows = cfg->n_replans * rows_per_replan;
+    nmpc::wb::WbArgs w = wb_args(h);
+    w.B = B; w.yref_per_stage = 1;
+    w.x0 = x0; w.yref = yref; w.yref_e = yref_e; w.params = params; w.X = X; w.U = U; w.status = status; w.stats = nullptr;
+    w.skip = r.term_mask ? failed : nullptr; w.skip_mask = r.term_mask;
+    const double dt_replan = cfg->replanning_steps * cfg->sim_dt, slack = 0.5 * cfg->sim_dt;
+    int last_node = cfg->last_node;
+    for (int i = 0; i < cfg->n_replans; ++i) {
+        const bool cold = cfg->first_solve && i == 0;
+        r.node = nodes[i];
+        r.first = cold ? 1 : 0;
+        r.replan_index = i;
+        r.row0 = i * rows_per_replan;
+        const double t_now = i * dt_replan;
+        r.push_dt = (push_force && cfg->push_duration > 0.0f && t_now >= (double)cfg->push_start - slack &&
+                     t_now < (double)cfg->push_start + (double)cfg->push_duration - slack) ? (float)dt_replan : 0.0f;
+        hipLaunchKernelGGL(nmpc::wb::nmpc_wb_rollout_prepare_kernel, dim3(B), dim3(64), 0, st, r);
+        int shift = cold ? 0 : nodes[i] - last_node;          // warm_start_solver(i_node): start_node = i_node - last_node (solver.py:304-309)
+        if (shift > N) shift = N;
+        last_node = nodes[i];
+        w.shift = shift;
+        w.max_sqp = cold ? cfg->max_sqp_first : h->max_sqp;
+        w.nlp_tol = cold ? cfg->nlp_tol_first : cfg->nlp_tol;
+        const int rc = launch_wb(h, w, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nmpc::wb::nmpc_wb_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, st, r);
     }
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;

@@ -159,7 +159,7 @@ class LocomotionMPC:
         simulation rate, follow it as if it were the plant.  q0, v0 in the solver's Euler layout.
         Returns q_traj[K(,B),18], one row per simulation step."""
         q, v = np.array(q0, float), np.array(v0, float)
-        sim_time, q_rows, time_traj = 0.0, [], None
+        sim_time, q_rows, v_rows, time_traj = 0.0, [], [], None
         while sim_time <= trajectory_time:
             if sim_time >= (self.current_opt_node + 1) * self.dt_nodes:
                 self.current_opt_node += 1
@@ -179,9 +179,105 @@ class LocomotionMPC:
                 self.plan_step = 0
             q, v = self.q_plan[self.plan_step].copy(), self.v_plan[self.plan_step].copy()
             q_rows.append(q)
+            v_rows.append(v)
             self._step()
             sim_time = sim_time + self.sim_dt
+        self.v_traj = np.stack(v_rows)                       # the velocities that go with the returned rows
         return np.stack(q_rows)
+
+    def replan_clock(self, trajectory_time: float):
+        """The float clock of `open_loop` without its solves: (number of simulation steps it runs, optimisation node of each
+        of its replans) from the controller's current counters -- what `open_loop_device` hands to the device, so that both
+        replan at the same nodes (the reference advances the node when the accumulated float time passes a node time,
+        mpc.py:171-186, 427-431)."""
+        sim_time, sim_step, node, nodes, steps = 0.0, self.sim_step, self.current_opt_node, [], 0
+        while sim_time <= trajectory_time:
+            if sim_time >= (node + 1) * self.dt_nodes:
+                node += 1
+            if sim_step % self.replanning_steps == 0:
+                nodes.append(node)
+            sim_step += 1
+            steps += 1
+            sim_time = sim_time + self.sim_dt
+        return steps, nodes, node
+
+    def state_rows(self, q_traj: np.ndarray, v_traj: np.ndarray, t0_step: int = 0) -> np.ndarray:
+        """states of this controller (Euler layout, [K, 18] each; K, B, 18 for a batch) as the reference's recorded rows
+        [phase, v_mj(18), q_mj[2:](17), base_wrt_feet(8)] (DAgger/utils/RolloutMPC.py:221): row j is the state after
+        simulation step t0_step + j"""
+        from .trajectory_io import convert_to_mujoco
+        q_traj, v_traj = np.asarray(q_traj, float), np.asarray(v_traj, float)
+        if q_traj.ndim == 3:
+            return np.stack([self.state_rows(q_traj[:, b], v_traj[:, b], t0_step) for b in range(q_traj.shape[1])])
+        period = self.config_gait.nominal_period
+        rows = np.zeros((len(q_traj), 44))
+        for j, (q, v) in enumerate(zip(q_traj, v_traj)):
+            q_mj, v_mj = convert_to_mujoco(q, v)
+            tw = (t0_step + j + 1) * self.sim_dt
+            bwf = (q[None, :2] - wb.feet_position_w(q)[:, :2]).reshape(8)
+            rows[j] = np.concatenate([[np.round(np.fmod(tw, period) / period, 4)], v_mj, q_mj[2:], bwf])
+        return rows
+
+    def open_loop_device(self, q0: np.ndarray, v0: np.ndarray, trajectory_time: float, push: Optional[dict] = None,
+                         record_sim_steps: bool = True, terminate_mask: int = 33, collision_height: float = 0.08):
+        """`open_loop` with the whole rollout on the device (nmpc_wb_rollout_batch): per replan the problem is assembled from
+        the plant state by a kernel, solved with the warm-start shift folded in, and the up-sampled plan is followed for
+        `replanning_steps` simulation steps -- one host call, no round trip per replan, the whole batch at once.
+        Returns S [B, K, 44] (device): the recorded rows of `state_rows` -- one per simulation step, K as `open_loop`
+        runs, or one per replan (the state it starts from) with record_sim_steps=False.  push = {"start", "duration",
+        "force": [B, 3]}: velocity impulse F dt / m on the base per replanning interval.  The controller's counters,
+        reference and solution views advance as in `open_loop`; `self.failed` holds the NMPC_ROLLOUT_FLAG_* bits,
+        `self.q_final` / `self.v_final` the plant state."""
+        import ctypes
+        import torch
+        from . import _lib
+        fs = self.solver
+        s = fs._device_solver()
+        B, N, dev = self.batch, self.config_opt.n_nodes, s.device
+        steps, nodes, node_end = self.replan_clock(trajectory_time)
+        n_replans = len(nodes)
+        cfg_o = self.config_opt
+        s.set_max_iter(cfg_o.max_iter); s.set_nlp_tol(cfg_o.nlp_tol); s.set_max_qp_iter(cfg_o.max_qp_iter)
+        fs._opts.update(max_iter=cfg_o.max_iter, nlp_tol=cfg_o.nlp_tol, qp_tol=cfg_o.qp_tol)
+        cfg = _lib.NmpcWbRolloutCfg(
+            n_replans, self.replanning_steps, self.contact_planner.nodes_per_cycle, int(self.first_solve), int(fs.last_node),
+            N_SQP_FIRST, cfg_o.nlp_tol / 10.0, cfg_o.nlp_tol, self.sim_dt, cfg_o.time_horizon, self.config_gait.nom_height,
+            self.height_offset, float(self.config_gait.step_height), float(push["start"]) if push else 0.0,
+            float(push["duration"]) if push else 0.0, int(record_sim_steps), int(fs.force_reference == "gravity_share"),
+            float(self.config_gait.nominal_period), int(terminate_mask), float(collision_height))
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float64).reshape(B, -1)), dtype=torch.float32).to(dev).contiguous()
+        t64 = lambda a: torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float64).reshape(B, -1)), dtype=torch.float64).to(dev).contiguous()
+        q, v = t32(q0), t32(v0)
+        v_des, w_des, ref_state = t64(self.v_des), t64(self.w_des), t64(self.base_ref_vel_tracking)
+        gait = torch.as_tensor(np.ascontiguousarray(self.contact_planner.gait_sequence), dtype=torch.int8).to(dev)
+        peaks = torch.as_tensor(np.ascontiguousarray(self.contact_planner.peak_swing), dtype=torch.int8).to(dev)
+        joint_ref = torch.as_tensor(self.joint_ref, dtype=torch.float32).to(dev).contiguous()
+        force = t32(push["force"]) if push else None
+        if getattr(self, "_X_dev", None) is None or self.first_solve:
+            self._X_dev = torch.zeros(B, N + 1, 42, dtype=torch.float32, device=dev)
+            self._U_dev = torch.zeros(B, N, 30, dtype=torch.float32, device=dev)
+        rows = n_replans * (self.replanning_steps if record_sim_steps else 1)
+        S = torch.empty(B, rows, 44, dtype=torch.float32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        failed = torch.zeros(B, dtype=torch.int32, device=dev)
+        nodes_c = (ctypes.c_int * n_replans)(*nodes)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(s.lib.nmpc_wb_rollout_batch(
+            s._h, B, ctypes.byref(cfg), p(gait), p(peaks), ctypes.cast(nodes_c, ctypes.c_void_p), p(q), p(v), p(v_des), p(w_des),
+            p(ref_state), p(joint_ref), p(force), p(self._X_dev), p(self._U_dev), p(S), p(status), p(failed),
+            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), s._h, "nmpc_wb_rollout_batch")
+        # bookkeeping as open_loop leaves it
+        self.first_solve = False
+        self.sim_step += steps
+        self.current_opt_node = node_end
+        fs.last_node = nodes[-1]
+        ref = ref_state.cpu().numpy()
+        # (open_loop integrates the reference once per simulation step it runs; the device does it per full replanning interval)
+        self.base_ref_vel_tracking = ref if self.batch > 1 else ref[0]
+        self.failed, self.status_dev = failed, status
+        self.q_final, self.v_final = q, v
+        fs.parse_sol(self._X_dev.cpu().numpy().astype(np.float64), self._U_dev.cpu().numpy().astype(np.float64))
+        return S[:, :steps] if record_sim_steps else S
 
     def _step(self) -> None:                                                                # mpc.py:183-186
         self.increment_base_ref_position()

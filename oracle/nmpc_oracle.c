@@ -127,7 +127,8 @@ enum { MP_DT = 0, MP_MASS, MP_IXX, MP_IYY, MP_IZZ, MP_GZ, MP_MU, MP_UMAX,
 /* option vector opt[13] */
 enum {
     OP_MAX_SQP = 0, OP_N_IPM, OP_NLP_TOL, OP_REG, OP_REG_E, OP_MU0, OP_SIGMA, OP_SMIN,
-    OP_GAMMA, OP_LINE_SEARCH, OP_RHO, OP_YREF_PER_STAGE, OP_TAU_MIN, OP_COUNT
+    OP_GAMMA, OP_LINE_SEARCH, OP_RHO, OP_YREF_PER_STAGE, OP_TAU_MIN,
+    OP_IPM_WARM, OP_WS_SFLOOR, OP_WS_LFLOOR, OP_WS_SHIFT, OP_WS_HAVE, OP_COUNT
 };
 
 int oracle_real_size(void) { return (int)sizeof(real); }
@@ -882,9 +883,24 @@ static real merit(int model_id, int nx, int nu, int np, int ng, int N, const rea
  * stats[4] = {cost at last linearisation, max|step|, alpha, sqp iterations}.
  * returns status 0 ok(converged), 1 NaN, 2 max iter, 4 qp failure.
  */
+int oracle_solve_ws(int model_id, int N, const real *mp, const real *opt, const real *W,
+                    const real *We, const real *x0, const real *yref, const real *yref_e,
+                    const real *params, real *X, real *U, real *stats, real *Sio, real *Lio);
 int oracle_solve(int model_id, int N, const real *mp, const real *opt, const real *W,
                  const real *We, const real *x0, const real *yref, const real *yref_e,
                  const real *params, real *X, real *U, real *stats) {
+    return oracle_solve_ws(model_id, N, mp, opt, W, We, x0, yref, yref_e, params, X, U, stats, NULL, NULL);
+}
+/* The same solve with the interior point's slacks and multipliers as in/out state, Sio / Lio [N][ng] (NULL: none).
+ * opt[OP_IPM_WARM] != 0: warm-started interior point (the reference: set_warm_start_inner_qp, warm_start_multipliers,
+ * solver.py:76-77,339) -- the multipliers of the previous QP solution are the starting point of the next one, across
+ * the SQP iterations of a call and, with opt[OP_WS_HAVE], across calls through the warm-start shift opt[OP_WS_SHIFT]
+ * (stage k starts from the previous call's stage k + shift; the exposed tail cold-starts).  As HPIPM's warm start does,
+ * the slacks are recomputed from the primal warm start, s = max(-c, s_floor), and the multipliers are kept,
+ * lam = max(lam_prev, lam_floor).  [decl] */
+int oracle_solve_ws(int model_id, int N, const real *mp, const real *opt, const real *W,
+                    const real *We, const real *x0, const real *yref, const real *yref_e,
+                    const real *params, real *X, real *U, real *stats, real *Sio, real *Lio) {
     int nx, nu, np, ng;
     if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
     const int ny = (model_id == 2) ? WB_NY : nx + nu;
@@ -965,11 +981,22 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
             qp_status = oracle_riccati(nx, nu, N, Q, R, q, r, A, Bm, d, dx0, dX, dU, NULL, NULL, NULL);
         } else {
             const real mu0 = opt[OP_MU0], sigma = opt[OP_SIGMA], smin = opt[OP_SMIN], gamma = opt[OP_GAMMA];
+            const int warm = opt[OP_IPM_WARM] != 0, ws_shift = (int)opt[OP_WS_SHIFT];
+            const real sfloor = opt[OP_WS_SFLOOR], lfloor = opt[OP_WS_LFLOOR];
             for (int k = 0; k < N; k++)
                 for (int j = 0; j < ng; j++) {
                     const size_t id = (size_t)k * MAXN + j;
-                    s[id] = -c[id] > smin ? -c[id] : smin;
-                    lam[id] = mu0 / s[id];
+                    int have = 0;
+                    real lprev = 0;
+                    if (warm && it > 0) { have = 1; lprev = lam[id]; }
+                    else if (warm && Lio && opt[OP_WS_HAVE] != 0 && k + ws_shift < N) { have = 1; lprev = Lio[(size_t)(k + ws_shift) * ng + j]; }
+                    if (have && act[id]) {
+                        s[id] = -c[id] > sfloor ? -c[id] : sfloor;
+                        lam[id] = lprev > lfloor ? lprev : lfloor;
+                    } else {
+                        s[id] = -c[id] > smin ? -c[id] : smin;
+                        lam[id] = mu0 / s[id];
+                    }
                 }
             memset(dX, 0, sizeof(real) * (N + 1) * nx);
             memset(dU, 0, sizeof(real) * N * nu);
@@ -1063,6 +1090,12 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
         if (opt[OP_NLP_TOL] > 0 && stepn < opt[OP_NLP_TOL]) { status = 0; it++; break; }
     }
     if (stats) { stats[0] = cost; stats[1] = stepn; stats[2] = alpha; stats[3] = (real)it; }
+    if (Sio && Lio)
+        for (int k = 0; k < N; k++)
+            for (int j = 0; j < ng; j++) {
+                Sio[(size_t)k * ng + j] = s[(size_t)k * MAXN + j];
+                Lio[(size_t)k * ng + j] = act[(size_t)k * MAXN + j] ? lam[(size_t)k * MAXN + j] : 0;
+            }
     free(Q); free(R); free(Rt); free(q); free(r); free(rt); free(A); free(Bm); free(d);
     free(dX); free(dU); free(dXp); free(dUp); free(G); free(c); free(s); free(lam); free(act);
     free(Xt); free(Ut);
@@ -1072,9 +1105,20 @@ int oracle_solve(int model_id, int N, const real *mp, const real *opt, const rea
 /* batch driver, OpenMP over problems (nthreads <= 0: runtime default).
  * Layouts batch-major: x0[B][nx], yref[B][N][ny] or [B][ny], yref_e[B][nx],
  * params[B][N+1][np], X[B][N+1][nx], U[B][N][nu], status[B], stats[B][4]. */
+int oracle_solve_batch_ws(int model_id, int N, int B, const real *mp, const real *opt, const real *W,
+                          const real *We, const real *x0, const real *yref, const real *yref_e,
+                          const real *params, real *X, real *U, int *status, real *stats, int nthreads,
+                          real *S, real *L);
 int oracle_solve_batch(int model_id, int N, int B, const real *mp, const real *opt, const real *W,
                        const real *We, const real *x0, const real *yref, const real *yref_e,
                        const real *params, real *X, real *U, int *status, real *stats, int nthreads) {
+    return oracle_solve_batch_ws(model_id, N, B, mp, opt, W, We, x0, yref, yref_e, params, X, U, status, stats, nthreads, NULL, NULL);
+}
+/* S, L: [B][N][ng] in/out interior-point state (NULL: none) */
+int oracle_solve_batch_ws(int model_id, int N, int B, const real *mp, const real *opt, const real *W,
+                          const real *We, const real *x0, const real *yref, const real *yref_e,
+                          const real *params, real *X, real *U, int *status, real *stats, int nthreads,
+                          real *S, real *L) {
     int nx, nu, np, ng;
     if (oracle_dims(model_id, &nx, &nu, &np, &ng)) return -1;
     int ny, nye;
@@ -1085,10 +1129,11 @@ int oracle_solve_batch(int model_id, int N, int B, const real *mp, const real *o
 #endif
 #pragma omp parallel for schedule(dynamic, 4)
     for (int b = 0; b < B; b++) {
-        status[b] = oracle_solve(model_id, N, mp, opt, W, We, x0 + (size_t)b * nx, yref + b * syr,
-                                 yref_e + (size_t)b * nye, params + (size_t)b * (N + 1) * np,
-                                 X + (size_t)b * (N + 1) * nx, U + (size_t)b * N * nu,
-                                 stats ? stats + (size_t)b * 4 : NULL);
+        status[b] = oracle_solve_ws(model_id, N, mp, opt, W, We, x0 + (size_t)b * nx, yref + b * syr,
+                                    yref_e + (size_t)b * nye, params + (size_t)b * (N + 1) * np,
+                                    X + (size_t)b * (N + 1) * nx, U + (size_t)b * N * nu,
+                                    stats ? stats + (size_t)b * 4 : NULL,
+                                    S ? S + (size_t)b * N * ng : NULL, L ? L + (size_t)b * N * ng : NULL);
     }
     return 0;
 }

@@ -19,9 +19,11 @@ MP_NAMES = ("dt", "mass", "Ixx", "Iyy", "Izz", "gz", "mu", "umax",
 MP_DEFAULTS = dict(dt=0.02, mass=15.0, Ixx=0.11, Iyy=0.27, Izz=0.33, gz=-9.81, mu=0.8, umax=0.0,
                    p_gain=50.0, hipx=0.19, hipy=0.047, lhip=0.095, l1=0.213, l2=0.213, res0=0.0, res1=0.0)
 OPT_NAMES = ("max_sqp_iter", "n_ipm", "nlp_tol", "reg", "reg_e", "mu0", "sigma", "s_min",
-             "gamma", "line_search", "rho", "yref_per_stage", "tau_min")
+             "gamma", "line_search", "rho", "yref_per_stage", "tau_min",
+             "ipm_warm", "ws_s_floor", "ws_lam_floor", "ws_shift", "ws_have")
 OPT_DEFAULTS = dict(max_sqp_iter=1, n_ipm=6, nlp_tol=0.0, reg=1e-6, reg_e=1e-5, mu0=10.0,
-                    sigma=0.2, s_min=1.0, gamma=0.995, line_search=0, rho=1e3, yref_per_stage=0, tau_min=0.1)
+                    sigma=0.2, s_min=1.0, gamma=0.995, line_search=0, rho=1e3, yref_per_stage=0, tau_min=0.1,
+                    ipm_warm=0, ws_s_floor=1e-2, ws_lam_floor=1e-2, ws_shift=0, ws_have=0)
 
 
 def build(force: bool = False) -> None:
@@ -119,8 +121,10 @@ class Oracle:
         st = self.lib.oracle_riccati(nx, nu, N, *[self._p(a) for a in (Q, R, q, r, A, B, d, dx0, dX, dU, K, kff, P)])
         return dict(status=st, dX=dX, dU=dU, K=K, kff=kff, P=P)
 
-    def solve_batch(self, model_id, N, mp, opt, W, We, x0, yref, yref_e, params, X, U, nthreads=0):
-        """Solves in place on copies; returns (X, U, status, stats)."""
+    def solve_batch(self, model_id, N, mp, opt, W, We, x0, yref, yref_e, params, X, U, nthreads=0, ipm_state=None):
+        """Solves in place on copies; returns (X, U, status, stats).
+        ipm_state: None, or a dict {"S", "L"} of [B, N, ng] arrays (slacks, multipliers of the interior point), read if
+        opt ws_have is set (warm start across calls, opt ipm_warm) and overwritten with the final state."""
         nx, nu, np_, _ = self.dims(model_id)
         x0 = self._a(x0)
         B = x0.shape[0]
@@ -138,10 +142,17 @@ class Oracle:
             assert params.shape == (B, N + 1, np_), params.shape
         status = np.zeros(B, np.int32)
         stats = np.zeros((B, 4), self.dtype)
-        rc = self.lib.oracle_solve_batch(model_id, N, B, *[self._p(self._a(a)) for a in (mp, opt, W, We)],
-                                         self._p(x0), self._p(yref), self._p(yref_e), self._p(params),
-                                         self._p(X), self._p(U), self._p(status), self._p(stats),
-                                         int(nthreads))
+        S = L = None
+        if ipm_state is not None:
+            ng = self.dims(model_id)[3]
+            S = self._a(ipm_state.get("S", np.zeros((B, N, ng))), (B, N, ng)).copy()
+            L = self._a(ipm_state.get("L", np.zeros((B, N, ng))), (B, N, ng)).copy()
+        rc = self.lib.oracle_solve_batch_ws(model_id, N, B, *[self._p(self._a(a)) for a in (mp, opt, W, We)],
+                                            self._p(x0), self._p(yref), self._p(yref_e), self._p(params),
+                                            self._p(X), self._p(U), self._p(status), self._p(stats),
+                                            int(nthreads), self._p(S), self._p(L))
+        if ipm_state is not None:
+            ipm_state["S"], ipm_state["L"] = S, L
         assert rc == 0
         return X, U, status, stats
 

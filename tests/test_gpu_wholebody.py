@@ -115,7 +115,7 @@ def test_wholebody_odd_batches_and_horizons(dev, oracle64, B, N):
     """ragged batches; the reference's own horizon (25 nodes, mpc_opt.py:11-13); the 64-lane limit of lane = stage"""
     w = wl.wholebody_trot(B=B, N=N, seed=7)
     s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2)
-    X, U, st, _ = _gpu_solve(s, w)
+    X, U, st, stats = _gpu_solve(s, w)
     Xo, Uo, sto, statso = _oracle_solve(oracle64, w, n_ipm=6, max_sqp_iter=2)
     assert np.array_equal(st, sto)
     assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))
@@ -374,3 +374,73 @@ def test_facade_open_loop_keeps_the_robot_up(dev):
     assert traj[-1, 0] > 0.01                                                      # it walks forward
     # five replans (steps 0, 40, .., 160); the node counter follows the float clock of the reference's loop
     assert mpc.current_opt_node in (4, 5) and mpc.solver.last_node in (3, 4) and not mpc.first_solve
+
+
+@pytest.mark.parametrize("force_reference", ["gravity_share", "zero"])
+def test_wholebody_device_rollout_equals_host_driven_open_loop(dev, force_reference):
+    """the reference's own problem through the reference's own loop (LocomotionMPC.open_loop,
+    mpc.py:416-462) from ONE host call -- per replan the problem is assembled on the device from the plant state, solved
+    with the warm-start shift folded in, the plan up-sampled and followed -- against the host-driven loop of the facade
+    (numpy helpers golden-pinned; same device solver): twelve replans, every recorded 44-slot row."""
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    T = 0.45
+    q0 = np.zeros(18); q0[2] = 0.30; q0[3] = 0.05; q0[6:] = wbk.Q_HOME
+    v0 = np.zeros(18); v0[0] = 0.1
+    out = {}
+    for mode in ("host", "device"):
+        mpc = LocomotionMPC(print_info=False, device=dev, force_reference=force_reference)
+        mpc.set_command(np.array([0.25, 0.05, 0.0]), 0.1)
+        if mode == "host":
+            q_traj = mpc.open_loop(q0, v0, T)
+            out[mode] = (mpc.state_rows(q_traj, mpc.v_traj), mpc.current_opt_node, mpc.solver.last_node, mpc.base_ref_vel_tracking.copy(),
+                         mpc.solver.q_sol_euler.copy())
+        else:
+            S = mpc.open_loop_device(q0, v0, T)
+            torch.cuda.synchronize()
+            out[mode] = (S.cpu().numpy()[0], mpc.current_opt_node, mpc.solver.last_node, mpc.base_ref_vel_tracking.copy(),
+                         mpc.solver.q_sol_euler.copy())
+            assert int(mpc.failed.cpu().numpy()[0] & 0xFF & ~16) == 0
+    (Sh, nh, lh, rh, qh), (Sd, nd, ld, rd, qd) = out["host"], out["device"]
+    assert Sh.shape == Sd.shape and Sh.shape[1] == 44 and Sh.shape[0] >= 440
+    assert (nh, lh) == (nd, ld), ((nh, lh), (nd, ld))                        # same float clock, same replanning nodes
+    assert np.array_equal(Sd[:, 0], Sh[:, 0].astype(np.float32))               # gait phase
+    e = rel(Sd, Sh)
+    print(f"whole-body device rollout vs host-driven open_loop ({force_reference}): rel-L2 {e:.2e} over {Sh.shape[0]} rows")
+    assert e < 2e-5, e
+    assert rel(qd, qh) < 2e-5                                                  # the last plan, in the facade's views
+    if force_reference == "gravity_share":
+        assert Sd[:, 19].min() > 0.22                                          # it stays up
+
+
+def test_wholebody_device_rollouts_batch_and_termination(dev):
+    """a batch of pushed whole-body rollouts: batch-size independence (a rollout is bit for bit what it is alone), flags,
+    early termination on the collision height, finite rows"""
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    B, T = 24, 0.8
+    rng = np.random.default_rng(2)
+    q0 = np.zeros((B, 18)); q0[:, 2] = 0.30; q0[:, 6:] = wbk.Q_HOME + rng.normal(0, 0.03, (B, 12))
+    v0 = np.zeros((B, 18))
+    force = rng.uniform(-1, 1, (B, 3)); force /= np.linalg.norm(force, axis=1, keepdims=True); force *= rng.uniform(50, 70, (B, 1))
+    force[0] = 0.0
+    force[1] = [0.0, 0.0, -70.0]
+    push = dict(start=0.2, duration=0.3, force=force)
+    mpc = LocomotionMPC(print_info=False, device=dev, batch=B, n_nodes=30, force_reference="gravity_share")
+    mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    S = mpc.open_loop_device(q0, v0, T, push=push, record_sim_steps=False)
+    torch.cuda.synchronize()
+    Sn, f = S.cpu().numpy(), mpc.failed.cpu().numpy()
+    assert Sn.shape[0] == B and Sn.shape[1] in (20, 21) and Sn.shape[2] == 44 and np.isfinite(Sn).all()     # (the float clock of the reference's loop)
+    assert (f & 1 == 0).all(), f                                               # no solver failure
+    assert f[0] >> 8 == 0 and (f[0] & 0x6F) == 0                               # the unpushed rollout: nothing but velocity tracking at the start
+    quat = Sn[:, :, 20:24]
+    assert np.allclose(np.linalg.norm(quat, axis=-1), 1.0, atol=1e-5)
+    for b in np.nonzero(f >> 8)[0]:                                             # terminated ones are frozen from the terminating row on
+        i = (f[b] >> 8) - 1
+        assert (Sn[b, i:] == Sn[b, i]).all() and Sn[b, i, 19] < 0.08
+    n = 3
+    small = LocomotionMPC(print_info=False, device=dev, batch=n, n_nodes=30, force_reference="gravity_share")
+    small.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    Ss = small.open_loop_device(q0[:n], v0[:n], T, push=dict(push, force=force[:n]), record_sim_steps=False)
+    assert np.array_equal(Ss.cpu().numpy(), Sn[:n]) and np.array_equal(small.failed.cpu().numpy(), f[:n])
