@@ -472,6 +472,19 @@ __device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
     }
 }
 
+// a lane shift inside the 16-lane rows (DPP row_shr:n = 0x110 + n: lane i reads lane i - n; row_shl:n = 0x100 + n: lane i + n);
+// lanes whose source falls outside their row read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lane row q (16 lanes) of the result takes lane row q + 1 of `a`, the last lane row takes lane row 0 of `b`: the rows 4(q+1)..
+// of a tile column, continued into the next tile, moved up by one quad (ds_bpermute: the LDS crossbar, no LDS memory)
+__device__ __forceinline__ float rows_up(float a, float b, int up_addr, bool last_row) {
+    const int x = __builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(a));
+    const int y = __builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(b));
+    return __int_as_float(last_row ? y : x);
+}
 __device__ __forceinline__ bool n_tile_nonzero(int k, int j) { return !((k == 0 && j == 0) || (k == 1 && j == 0) || (k == 1 && j == 1)); }
 __device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 && j == 1); }
 
@@ -759,6 +772,14 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         }
     }
     if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
+    // constants of the identity blocks of B~ (see the backward stage): dt^2, on columns 0, 1 of a tile, on rows 0, 1 of a tile
+    const float dt2 = dt * dt;
+    const float dt2_c01 = (c < 2) ? dt2 : 0.0f;
+    const int up_addr = 4 * ((lane + 16) & 63);
+    const bool last_row = lane >= 48;
+    float dt2_r01[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
 
     bool qp_ok = true;
     for (int ii = 0; ii < n_sweeps; ++ii) {
@@ -818,24 +839,43 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             WB_STAMP(1);
             // ---- P~A~ = P~ + P~N~ ,  P~B~
+            // Where a tile of N~ or B~ holds nothing but the integrator's identities -- N~(0,1): dt at (q_r, v_r); B~(.,0): dt^2 at
+            // (q_c, a_c) and dt at (v_c, a_c) -- the product with P~ is a COLUMN SHIFT of P~ by 18 = 16 + 2 columns: a lane shift
+            // by two inside the 16-lane rows of the accumulator layout (DPP row_shr / row_shl, no matrix instruction).  Every
+            // output element has the same non-zero terms in the same order as the MFMA chain had (its other terms were exact
+            // zeros), so the results are bit-identical: 48 of the 132 MFMAs of this segment become 48 VALU operations.
             f32x4 PA[XT][XT], PB[XT][UT];
 #pragma unroll
             for (int i = 0; i < XT; ++i) {
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
                     f32x4 acc = P[i][j];
+                    if (j == 1) {            // kk = 0: (P~ N~)[:, 18 + c] = dt P~[:, c], c <= 13
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(dt, dpp_row<0x112>(P[i][0][r]), acc[r]);      // row_shr:2
+                    }
 #pragma unroll
                     for (int kk = 0; kk < XT; ++kk)
-                        if (n_tile_nonzero(kk, j)) acc = xty(P[kk][i], Nt[kk][j], acc);
+                        if (n_tile_nonzero(kk, j) && !(kk == 0 && j == 1)) acc = xty(P[kk][i], Nt[kk][j], acc);
                     PA[i][j] = acc;
                 }
+                {   // j = 0 (inputs a_0..a_15): (P~ B~)[:, a_c] = dt^2 P~[:, c] + dt P~[:, 18 + c]
+                    f32x4 acc;
 #pragma unroll
-                for (int j = 0; j < UT; ++j) {
-                    f32x4 acc = zero4();
+                    for (int r = 0; r < 4; ++r) {
+                        float t = dt2 * P[i][0][r];
+                        t = __builtin_fmaf(dt, dpp_row<0x102>(P[i][1][r]), t);      // row_shl:2: columns 18..31 of P~ onto lanes 0..13
+                        t = __builtin_fmaf(dt, dpp_row<0x11E>(P[i][2][r]), t);      // row_shr:14: columns 32, 33 onto lanes 14, 15
+                        acc[r] = t;
+                    }
+                    PB[i][0] = acc;
+                }
+                {   // j = 1 (a_16, a_17, f): B~(1,1) holds nothing but dt^2 at (q_16, a_16), (q_17, a_17) -- columns 16, 17 of P~ in
+                    // place, scaled; the rest (dt at v_16, v_17 and the wrench map of the forces) is the tile B~(2,1)
+                    f32x4 acc;
 #pragma unroll
-                    for (int kk = 0; kk < XT; ++kk)
-                        if (b_tile_nonzero(kk, j)) acc = xty(P[kk][i], Bt[kk][j], acc);
-                    PB[i][j] = acc;
+                    for (int r = 0; r < 4; ++r) acc[r] = dt2_c01 * P[i][1][r];
+                    PB[i][1] = xty(P[2][i], Bt[2][1], acc);
                 }
             }
             WB_STAMP(2);
@@ -861,9 +901,36 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                         for (int r = 0; r < 4; ++r) Huu[i][j][r] = rdiag[i][r] + (i == 1 ? ik[rIdx[r]] : 0.0f);
                     }
                 }
+                // kk = i: B~(i,i) is dt^2 on its diagonal (all of it for i = 0, rows a_16, a_17 for i = 1) -- B~(i,i)' X is X scaled
+                // in place, the first term of every element as in the MFMA chain it replaces
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = (i == 0) ? dt2 : dt2_r01[r];
+#pragma unroll
+                    for (int j = 0; j < XT; ++j) Hux[i][j][r] = __builtin_fmaf(sc, PA[i][j][r], Hux[i][j][r]);
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) Huu[i][j][r] = __builtin_fmaf(sc, PB[i][j][r], Huu[i][j][r]);
+                }
+                if (i == 0) {
+                    // kk = 1, 2 for the inputs a_0..a_15: B~(1,0), B~(2,0) hold nothing but dt at (v_c, a_c) -- row 18 + c of X onto
+                    // row c.  In the accumulator layout rows 18 + 4q + r are registers 2, 3 of the same lane (r = 0, 1) and
+                    // registers 0, 1 one lane row (16 lanes) further on (r = 2, 3; the last lane row takes rows 32, 33 from tile
+                    // row 2): one crossbar move per such register, no matrix instruction
+#pragma unroll
+                    for (int j = 0; j < XT; ++j) {
+                        Hux[0][j][0] = __builtin_fmaf(dt, PA[1][j][2], Hux[0][j][0]);
+                        Hux[0][j][1] = __builtin_fmaf(dt, PA[1][j][3], Hux[0][j][1]);
+                        Hux[0][j][2] = __builtin_fmaf(dt, rows_up(PA[1][j][0], PA[2][j][0], up_addr, last_row), Hux[0][j][2]);
+                        Hux[0][j][3] = __builtin_fmaf(dt, rows_up(PA[1][j][1], PA[2][j][1], up_addr, last_row), Hux[0][j][3]);
+                    }
+                    Huu[0][0][0] = __builtin_fmaf(dt, PB[1][0][2], Huu[0][0][0]);
+                    Huu[0][0][1] = __builtin_fmaf(dt, PB[1][0][3], Huu[0][0][1]);
+                    Huu[0][0][2] = __builtin_fmaf(dt, rows_up(PB[1][0][0], PB[2][0][0], up_addr, last_row), Huu[0][0][2]);
+                    Huu[0][0][3] = __builtin_fmaf(dt, rows_up(PB[1][0][1], PB[2][0][1], up_addr, last_row), Huu[0][0][3]);
+                }
 #pragma unroll
                 for (int kk = 0; kk < XT; ++kk)
-                    if (b_tile_nonzero(kk, i)) {
+                    if (b_tile_nonzero(kk, i) && kk != i && i != 0) {
 #pragma unroll
                         for (int st = 0; st < 4; ++st) {
 #pragma unroll
