@@ -461,14 +461,21 @@ __device__ __forceinline__ void ldl_update(float (&X)[NU], float wx) {
     }
 }
 template <int J, unsigned MASK>
-__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
+__device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok, const float (&rs_free)[12]) {
     if constexpr (J < NU) {
-        const float d = bcast(X[J], J);
-        ok = ok && (d > 0.0f);
-        const float rs = __builtin_amdgcn_rsqf(d);
-        X[J] *= rs;
-        if constexpr (((MASK >> J) & 1u) && coupled_rows_above(MASK, J) > 0) ldl_update<J, MASK>(X, X[J] * rs);
-        ldl_pivots<J + 1, MASK>(X, ok);
+        if constexpr ((MASK >> J) & 1u) {
+            const float d = bcast(X[J], J);
+            ok = ok && (d > 0.0f);
+            const float rs = __builtin_amdgcn_rsqf(d);
+            X[J] *= rs;
+            if constexpr (coupled_rows_above(MASK, J) > 0) ldl_update<J, MASK>(X, X[J] * rs);
+        } else {
+            // a decoupled input (a force component of a swing foot): nothing of B~'P~B~ or of the barrier reaches its pivot, which
+            // is the constant W_f_reg + reg -- its 1 / sqrt comes from the kernel's prologue (the same v_rsq of the same bits)
+            // instead of a v_readlane -> v_rsq on the elimination's dependent chain
+            X[J] *= rs_free[J >= WF ? J - WF : 0];
+        }
+        ldl_pivots<J + 1, MASK>(X, ok, rs_free);
     }
 }
 
@@ -477,6 +484,19 @@ __device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok) {
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// the same, for the lanes of bank 0 (lanes 0..3 of every row) only; the others read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_bank0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0x1, true));
+}
+// sum over the 16 lanes of a lane row, in every lane of it (the first four steps of wave_reduce)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_row<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_row<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_row<0x141>(v);     // row_half_mirror
+    v += dpp_row<0x140>(v);     // row_mirror
+    return v;
 }
 // lane row q (16 lanes) of the result takes lane row q + 1 of `a`, the last lane row takes lane row 0 of `b`: the rows 4(q+1)..
 // of a tile column, continued into the next tile, moved up by one quad (ds_bpermute: the LDS crossbar, no LDS memory)
@@ -500,7 +520,7 @@ __device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 &
 // QP + step of one SQP iteration: one problem per wavefront.
 __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #ifdef NMPC_WB_STAMPS
-    unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_readcyclecounter(), st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
@@ -773,10 +793,21 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     }
     if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
     // constants of the identity blocks of B~ (see the backward stage): dt^2, on columns 0, 1 of a tile, on rows 0, 1 of a tile
+    // 1 / sqrt of the pivot of a decoupled force input, by component: Huu[j][j] = (W_f_reg + reg) + 0 there (see ldl_pivots)
+    float rs_free[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) rs_free[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
     const float dt2 = dt * dt;
     const float dt2_c01 = (c < 2) ? dt2 : 0.0f;
     const int up_addr = 4 * ((lane + 16) & 63);
     const bool last_row = lane >= 48;
+    const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
+    const float dt_q0 = (q4 == 0) ? dt : 0.0f;
+    const bool hx_col = (c == HX - 32), hx_row = (q4 == 2);       // HX = 42: column 10 of tile column 2; row 10 of tile row 2 = quad 2, register 2
+    // where this lane finds, in the stage record, the defects of its columns (one per tile column) ...
+    int dcolIdx[XT];
+#pragma unroll
+    for (int kk = 0; kk < XT; ++kk) dcolIdx[kk] = (16 * kk + c < NX) ? R_D + 16 * kk + c : R_ZERO;
     float dt2_r01[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
@@ -796,6 +827,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (size_t)(N - 1) * REC + (4 * lane < REC ? 4 * lane : 0));
             *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
         }
+        // The record of stage k-1 is requested in the middle of stage k+1, next to the Q~ tiles -- BEFORE that stage's K~ stores.
+        // vmcnt retires in order: requested at the top of stage k (behind the six K~ stores of stage k+1), waiting for it meant
+        // waiting for those stores to reach memory, every stage (s_waitcnt vmcnt(0) in the middle of the stage).
+        f32x4 rec_pref = *reinterpret_cast<const f32x4*>(recs + (size_t)(N > 1 ? N - 2 : 0) * REC + (4 * lane < REC ? 4 * lane : 0));
         wave_sync();
         // Q~ tiles (lower ones) are requested one and a half stages ahead of their use: for stage k-1 in the middle of
         // stage k.  (A timing build that reads one cache-resident image instead of each stage's own ran 10 % faster:
@@ -809,7 +844,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             const int kn = k > 0 ? k - 1 : 0;
             // prefetch: next record, this stage's Q~ tiles were requested ... (Q of stage k is loaded here; the
             // loads are issued first and consumed after the P~A~, P~B~ products)
-            const f32x4 rec_next = *reinterpret_cast<const f32x4*>(recs + (size_t)kn * REC + (4 * lane < REC ? 4 * lane : 0));
+            const f32x4 rec_next = rec_pref;
             f32x4 Q[XT][XT];
 #pragma unroll
             for (int i = 0; i < XT; ++i)
@@ -828,14 +863,26 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
                 Nt[0][0] = Nt[1][0] = Nt[1][1] = zero4();
                 Bt[0][1] = zero4();
+                Nt[0][2] = Nt[1][2] = Nt[2][2] = zero4();       // (their products are formed without the matrix pipe, see below)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
+                    if (nt_j[t] != 2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Nt[nt_i[t]][nt_j[t]][r] = rk[nIdx[t][r]];
+                        for (int r = 0; r < 4; ++r) Nt[nt_i[t]][nt_j[t]][r] = rk[nIdx[t][r]];
+                    }
 #pragma unroll
                 for (int t = 0; t < BT; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Bt[bt_i[t]][bt_j[t]][r] = rk[bIdx[t][r]];
+            }
+            // the defect of the stage: by column of this lane (P~ d) and by row quad of this lane (d'(P~A~)); d[42], d[43] are zero
+            float dcol[XT], drow[XT][4];
+#pragma unroll
+            for (int kk = 0; kk < XT; ++kk) {
+                dcol[kk] = rk[dcolIdx[kk]];
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(rk + R_D + ((16 * kk + 4 * q4 < 44) ? 16 * kk + 4 * q4 : 40));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) drow[kk][r] = (16 * kk + 4 * q4 < 44) ? d4[r] : 0.0f;
             }
             WB_STAMP(1);
             // ---- P~A~ = P~ + P~N~ ,  P~B~
@@ -854,9 +901,25 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(dt, dpp_row<0x112>(P[i][0][r]), acc[r]);      // row_shr:2
                     }
+                    if (j == 2) {
+                        // the tiles N~(.,2) hold dt at (q_14..q_17, v_14..v_17) -- column shifts as above -- and the defect d in the
+                        // homogeneous column: (P~ N~)[:, HX] = P~ d, one column from a contraction over all 42 states.  On the
+                        // matrix pipe that column costs 36 MFMAs per stage; here every lane multiplies its row quad of P~ with the
+                        // defects of its columns (three fma per register) and the 16 lanes of a row add up (four DPP steps)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[r] = __builtin_fmaf(dt, dpp_row<0x10E>(P[i][0][r]), acc[r]);              // row_shl:14: columns 14, 15 -> 32, 33
+                            acc[r] = __builtin_fmaf(dt, dpp_row_bank0<0x112>(P[i][1][r]), acc[r]);        // row_shr:2, lanes 2, 3: columns 16, 17 -> 34, 35
+                            float t = P[i][0][r] * dcol[0];
+                            t = __builtin_fmaf(P[i][1][r], dcol[1], t);
+                            t = __builtin_fmaf(P[i][2][r], dcol[2], t);
+                            t = row_sum16(t);
+                            acc[r] += hx_col ? t : 0.0f;
+                        }
+                    }
 #pragma unroll
                     for (int kk = 0; kk < XT; ++kk)
-                        if (n_tile_nonzero(kk, j) && !(kk == 0 && j == 1)) acc = xty(P[kk][i], Nt[kk][j], acc);
+                        if (n_tile_nonzero(kk, j) && !(kk == 0 && j == 1) && j != 2) acc = xty(P[kk][i], Nt[kk][j], acc);
                     PA[i][j] = acc;
                 }
                 {   // j = 0 (inputs a_0..a_15): (P~ B~)[:, a_c] = dt^2 P~[:, c] + dt P~[:, 18 + c]
@@ -958,14 +1021,37 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i) {
 #pragma unroll
                 for (int j = 0; j <= i; ++j) H[i][j] = Q[i][j] + PA[i][j];
+                if (i == 2) {
+                    // N~(.,2)'(P~A~): rows v_14..v_17 = dt x rows q_14..q_17 of P~A~ (quad 3 of tile row 0 and quad 0 of tile row 1 onto
+                    // quad 0 of tile row 2), and the homogeneous row = d'(P~A~): every lane adds up its row quads against the
+                    // defects of its rows (twelve fma per column tile), the four lane rows of a column meet through the crossbar
 #pragma unroll
-                for (int kk = 0; kk < XT; ++kk)
-                    if (n_tile_nonzero(kk, i)) {
+                    for (int j = 0; j < XT; ++j) {
+                        const float v14 = __int_as_float(__builtin_amdgcn_ds_bpermute(q3_addr, __float_as_int(PA[0][j][2])));
+                        const float v15 = __int_as_float(__builtin_amdgcn_ds_bpermute(q3_addr, __float_as_int(PA[0][j][3])));
+                        H[2][j][0] = __builtin_fmaf(dt_q0, v14, H[2][j][0]);
+                        H[2][j][1] = __builtin_fmaf(dt_q0, v15, H[2][j][1]);
+                        H[2][j][2] = __builtin_fmaf(dt_q0, PA[1][j][0], H[2][j][2]);
+                        H[2][j][3] = __builtin_fmaf(dt_q0, PA[1][j][1], H[2][j][3]);
+                        float t = 0.0f;
 #pragma unroll
-                        for (int st = 0; st < 4; ++st)
+                        for (int kk = 0; kk < XT; ++kk)
 #pragma unroll
-                            for (int j = 0; j <= i; ++j) H[i][j] = mfma4(Nt[kk][i][st], PA[kk][j][st], H[i][j]);
+                            for (int r = 0; r < 4; ++r) t = __builtin_fmaf(drow[kk][r], PA[kk][j][r], t);
+                        t += __int_as_float(__builtin_amdgcn_ds_bpermute(x16_addr, __float_as_int(t)));
+                        t += __int_as_float(__builtin_amdgcn_ds_bpermute(x32_addr, __float_as_int(t)));
+                        H[2][j][2] += hx_row ? t : 0.0f;
                     }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < XT; ++kk)
+                        if (n_tile_nonzero(kk, i)) {
+#pragma unroll
+                            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                                for (int j = 0; j <= i; ++j) H[i][j] = mfma4(Nt[kk][i][st], PA[kk][j][st], H[i][j]);
+                        }
+                }
 #pragma unroll
                 for (int j = 0; j <= i; ++j) *reinterpret_cast<f32x4*>(hbuf + (16 * j + c) * LDH + 16 * i + 4 * q4) = H[i][j];
             }
@@ -994,16 +1080,17 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             bool ok = true;
             {
-                if (pat == 0x9u) ldl_pivots<0, coupling_mask(0x9u)>(Xc, ok);
-                else if (pat == 0x6u) ldl_pivots<0, coupling_mask(0x6u)>(Xc, ok);
-                else if (pat == 0x0u) ldl_pivots<0, coupling_mask(0x0u)>(Xc, ok);
-                else ldl_pivots<0, coupling_mask(0xFu)>(Xc, ok);
+                if (pat == 0x9u) ldl_pivots<0, coupling_mask(0x9u)>(Xc, ok, rs_free);
+                else if (pat == 0x6u) ldl_pivots<0, coupling_mask(0x6u)>(Xc, ok, rs_free);
+                else if (pat == 0x0u) ldl_pivots<0, coupling_mask(0x0u)>(Xc, ok, rs_free);
+                else ldl_pivots<0, coupling_mask(0xFu)>(Xc, ok, rs_free);
             }
             qp_ok = qp_ok && ok;
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)kn * QT_FLOATS + (i * XT + j) * IMG, lane);
+            rec_pref = *reinterpret_cast<const f32x4*>(recs + (size_t)(k > 1 ? k - 2 : 0) * REC + (4 * lane < REC ? 4 * lane : 0));
             WB_STAMP(5);
             // transposed tiles: Ht[i][j] = (lower tile (i,j))', i >= j
             f32x4 Ht[XT][XT];
@@ -1075,6 +1162,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     for (int i = 0; i < XT; ++i)
 #pragma unroll
                         for (int j = 0; j <= i; ++j) P[i][j] = mfma4(nY[kk][i][st], Y[kk][j][st], P[i][j]);
+            WB_STAMP(16);      // P~+ products
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (c == HX - 32 && 32 + 4 * q4 + r == HX) P[2][2][r] = 0.0f;
@@ -1090,6 +1178,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     const float* ph = hbuf + (16 * j + 4 * q4) * LDH + 16 * i + c;
                     P[j][i] = f32x4{ph[0], ph[LDH], ph[2 * LDH], ph[3 * LDH]};
                 }
+            WB_STAMP(17);      // mirror of P~+ through the LDS
             {
                 f32x4 Kt[UT][XT];
 #pragma unroll
@@ -1114,112 +1203,112 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                         store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
                     }
             }
+            WB_STAMP(18);      // K~ products and stores
         }
         WB_STAMP(8);
         phase_sync();
         // ------------------------------------------------------------ phase F: forward sweep
+        // du = K~ dx~ row per lane, dx+ from the model's sparse structure -- with dx~ and the force part of du WAVE-UNIFORM in
+        // scalar registers (v_readlane broadcasts) and the two lane-shifted terms of the kinematic rows through one crossbar
+        // move: no LDS round trip on the stage-to-stage chain (the version that kept dx~, du in the LDS spent 4.4 k cycles
+        // per stage in three dependent write -> fence -> read trips; this one is bit-identical to it).  Gain rows are
+        // requested FWD_PF stages ahead in a register ring, the stage record two stages ahead (registers -> LDS).
         float* oX = use_ipm ? dXp : dX;
         float* oU = use_ipm ? dUp : dU;
-        {
-            float v = 0.0f;
-            if (lane < NX) v = x0[lane] - Xg[lane];       // node 0 is not moved by the warm-start shift
-            if (lane == HX) v = 1.0f;
-            if (lane < 48) dxv[lane] = v;
-            if (lane < 32) duv[lane] = 0.0f;
-            if (lane < NX) AT(oX, 0, lane) = v;
-        }
-        {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (4 * lane < REC ? 4 * lane : 0));
-            *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
-        }
+        float xcur = 0.0f;                                  // lane i < 42: dx_i; lane 42: the homogeneous 1
+        if (lane < NX) xcur = x0[lane] - Xg[lane];          // node 0 is not moved by the warm-start shift
+        if (lane == HX) xcur = 1.0f;
+        if (lane < NX) AT(oX, 0, lane) = xcur;
+        float* const rbuf[2] = {recb, hbuf};                // stage records, double-buffered (hbuf is free in this phase)
+        const unsigned rec_lane = (4 * lane < REC) ? 4 * lane : 0;
+        auto load_rec = [&](int k) { return *reinterpret_cast<const f32x4*>(recs + (size_t)(k < N ? k : N - 1) * REC + rec_lane); };
+        *reinterpret_cast<f32x4*>(rbuf[0] + 4 * lane) = load_rec(0);
+        f32x4 rec_ahead = load_rec(1);                      // the record of stage k + 1 while stage k runs
         wave_sync();
-        // row `lane` of K~ in the tile image: tile (lane/16, j/16), element (lane%16, j%16).  The row of the next stage is
-        // requested before this stage's is used (a stage is far shorter than a trip to the L2 / HBM: unprefetched, the
-        // forward sweep cost 6.9 k cycles per stage against 27 k for the backward stage).  Measured and dropped (same box,
-        // tools/ab_wb.sh): three rows in flight (two stages ahead), in either load order, -5 ... -7 % on the whole solve.
         const int urow = lane < NU ? lane : 0;
         const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
         auto load_krow = [&](int k, float (&row)[HX + 1]) {
-            const float* Kk = Kimg + (size_t)k * KT_FLOATS + krow_off;
+            const float* Kk = Kimg + (size_t)(k < N ? k : N - 1) * KT_FLOATS + krow_off;
 #pragma unroll
             for (int j = 0; j <= HX; ++j) row[j] = Kk[(j >> 4) * IMG + (j & 15) * TS];
         };
-        auto fwd_stage = [&](int k, const float (&row)[HX + 1], float (&row_next)[HX + 1]) {
-            const int kn = k + 1 < N ? k + 1 : k;
-            load_krow(kn, row_next);
-            const f32x4 rec_next = *reinterpret_cast<const f32x4*>(recs + (size_t)kn * REC + (4 * lane < REC ? 4 * lane : 0));
+        const int fi = lane < NX ? lane : 0;
+        const int hr = (fi >= 39) ? fi - 39 : 0, lr = (fi >= 36 && fi < 39) ? fi - 36 : 0;
+        const int x_addr = 4 * (lane < 18 ? lane + 18 : (lane < 36 ? lane - 18 : lane));      // q rows take dx of their v row, v rows du of their q row
+        constexpr int FWD_PF = 2;
+        float ring[FWD_PF][HX + 1];
+#pragma unroll
+        for (int pf = 0; pf < FWD_PF; ++pf) load_krow(pf, ring[pf]);
+        auto fwd_stage = [&](int k, float (&row)[HX + 1]) {
+            const float* rk = rbuf[k & 1];
+            const f32x4 rec_next = rec_ahead;                // stage k + 1's record, requested a stage ago
+            rec_ahead = load_rec(k + 2);
+            // what this lane needs of the stage record (not on the dependent chain: the record has been in the LDS for a stage)
+            const float d_i = rk[R_D + fi];
+            f32x4 hq4[4], hf4[3];
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) hq4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HQ + hr * 16 + 4 * v4);
+#pragma unroll
+            for (int v4 = 0; v4 < 3; ++v4) hf4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12 + 4 * v4);
+            const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
+            float dxs[HX];
+#pragma unroll
+            for (int j = 0; j < HX; ++j) dxs[j] = bcast(xcur, j);
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
             for (int j4 = 0; j4 < 11; ++j4) {
-                const f32x4 dx = *reinterpret_cast<const f32x4*>(dxv + 4 * j4);      // broadcast read
-                a0 = fmaf(row[4 * j4], dx[0], a0);
-                a1 = fmaf(row[4 * j4 + 1], dx[1], a1);
-                a2 = fmaf(row[4 * j4 + 2], dx[2], a2);
-                if (4 * j4 + 3 <= HX) a3 = fmaf(row[(4 * j4 + 3 <= HX) ? 4 * j4 + 3 : 0], dx[3], a3);
+                a0 = fmaf(row[4 * j4], dxs[4 * j4], a0);
+                a1 = fmaf(row[4 * j4 + 1], dxs[4 * j4 + 1], a1);
+                a2 = fmaf(row[4 * j4 + 2], (4 * j4 + 2 < HX) ? dxs[4 * j4 + 2 < HX ? 4 * j4 + 2 : 0] : 1.0f, a2);      // dx~[HX] = 1
+                if (4 * j4 + 3 <= HX) a3 = fmaf(row[(4 * j4 + 3 <= HX) ? 4 * j4 + 3 : 0], dxs[(4 * j4 + 3 < HX) ? 4 * j4 + 3 : 0], a3);
             }
             const float du = (a0 + a1) + (a2 + a3);
+            load_krow(k + FWD_PF, row);                      // refill the ring slot after its last use
             WB_STAMP(13);
-            if (lane < NU) { duv[lane] = du; AT(oU, k, lane) = du; }
-            wave_sync();
-            const float* rk = recb;
-            float xn = 0.0f;
-            {
-                const int i = lane < NX ? lane : 0;
-                xn = dxv[i] + rk[R_D + i];
-                // kinematic rows: one or two terms at lane-dependent places (clamped, selected)
-                const float t_q = dt * dxv[i < 18 ? i + 18 : 0] + dt * dt * duv[i < 18 ? i : 0];
-                const float t_v = dt * duv[(i >= 18 && i < 36) ? i - 18 : 0];
-                xn += (i < 18) ? t_q : (i < 36) ? t_v : 0.0f;
-                // momentum rows 36..41 (every lane runs the code on a clamped row; six lanes keep the result):
-                // linear rows: sum_f cdt_f duf[3f + i-36]; angular rows: Hq[i-39] . dx[3..17] + Hf[i-39] . duf
-                const int hr = (i >= 39) ? i - 39 : 0, lr = (i >= 36 && i < 39) ? i - 36 : 0;
-                float acc_a = 0.0f, acc_l = 0.0f;
-                const f32x4* hq4 = reinterpret_cast<const f32x4*>(rk + R_HQ + hr * 16);
-                const f32x4* hf4 = reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12);
-                const f32x4* dx4 = reinterpret_cast<const f32x4*>(dxv);
-                const f32x4* du4 = reinterpret_cast<const f32x4*>(duv);
-                float dxs[20], dus[16];
+            if (lane < NU) AT(oU, k, lane) = du;
+            float duf[12];
 #pragma unroll
-                for (int v4 = 0; v4 < 5; ++v4) { const f32x4 t4 = dx4[v4]; dxs[4 * v4] = t4[0]; dxs[4 * v4 + 1] = t4[1]; dxs[4 * v4 + 2] = t4[2]; dxs[4 * v4 + 3] = t4[3]; }
+            for (int j = 0; j < 12; ++j) duf[j] = bcast(du, WF + j);
+            const float other = __int_as_float(__builtin_amdgcn_ds_bpermute(x_addr, __float_as_int(lane >= 18 ? xcur : du)));
+            float xn = xcur + d_i;
+            // kinematic rows: q+ = q + dt v + dt^2 a, v+ = v + dt a
+            const float t_q = dt * other + dt * dt * du;
+            const float t_v = dt * other;
+            xn += (fi < 18) ? t_q : (fi < 36) ? t_v : 0.0f;
+            // momentum rows 36..41 (every lane runs the code on a clamped row; six lanes keep the result):
+            // linear rows: sum_f cdt_f duf[3f + i-36]; angular rows: Hq[i-39] . dx[3..17] + Hf[i-39] . duf
+            float acc_a = 0.0f, acc_l = 0.0f;
 #pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) { const f32x4 t4 = du4[4 + v4]; dus[4 * v4] = t4[0]; dus[4 * v4 + 1] = t4[1]; dus[4 * v4 + 2] = t4[2]; dus[4 * v4 + 3] = t4[3]; }
+            for (int v4 = 0; v4 < 4; ++v4)
 #pragma unroll
-                for (int v4 = 0; v4 < 4; ++v4) {
-                    const f32x4 h4 = hq4[v4];
+                for (int r = 0; r < 4; ++r)
+                    if (4 * v4 + r < 15) acc_a = fmaf(hq4[v4][r], dxs[3 + 4 * v4 + r], acc_a);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * v4 + r < 15) acc_a = fmaf(h4[r], dxs[3 + 4 * v4 + r], acc_a);
-                }
+            for (int v4 = 0; v4 < 3; ++v4)
 #pragma unroll
-                for (int v4 = 0; v4 < 3; ++v4) {
-                    const f32x4 h4 = hf4[v4];
+                for (int r = 0; r < 4; ++r) acc_a = fmaf(hf4[v4][r], duf[4 * v4 + r], acc_a);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc_a = fmaf(h4[r], dus[2 + 4 * v4 + r], acc_a);      // duf[f] = duv[18 + f]
-                }
-                const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float sel = lr == 0 ? dus[2 + 3 * f] : lr == 1 ? dus[3 + 3 * f] : dus[4 + 3 * f];
-                    acc_l = fmaf(cd[f], sel, acc_l);
-                }
-                xn += (i >= 39) ? acc_a : (i >= 36) ? acc_l : 0.0f;
+            for (int f = 0; f < 4; ++f) {
+                const float sel = lr == 0 ? duf[3 * f] : lr == 1 ? duf[3 * f + 1] : duf[3 * f + 2];
+                acc_l = fmaf(cd[f], sel, acc_l);
             }
+            xn += (fi >= 39) ? acc_a : (fi >= 36) ? acc_l : 0.0f;
             WB_STAMP(14);
-            wave_sync();
-            if (lane < NX) { dxv[lane] = xn; AT(oX, k + 1, lane) = xn; }
-            *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_next;
+            if (lane < NX) AT(oX, k + 1, lane) = xn;
+            xcur = (lane < NX) ? xn : (lane == HX ? 1.0f : 0.0f);
+            *reinterpret_cast<f32x4*>(rbuf[(k + 1) & 1] + 4 * lane) = rec_next;
             wave_sync();
             WB_STAMP(15);
         };
         {
-            float rowA[HX + 1], rowB[HX + 1];
-            load_krow(0, rowA);
             int k = 0;
-            for (; k + 2 <= N; k += 2) {
-                fwd_stage(k, rowA, rowB);
-                fwd_stage(k + 1, rowB, rowA);
+            for (; k + FWD_PF <= N; k += FWD_PF) {
+#pragma unroll
+                for (int pf = 0; pf < FWD_PF; ++pf) fwd_stage(k + pf, ring[pf]);
             }
-            if (k < N) fwd_stage(k, rowA, rowB);
+#pragma unroll
+            for (int pf = 0; pf < FWD_PF - 1; ++pf)
+                if (k + pf < N) fwd_stage(k + pf, ring[pf]);
         }
         phase_sync();
         WB_STAMP(9);
@@ -1325,7 +1414,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     }
 #ifdef NMPC_WB_STAMPS
     WB_STAMP(11);
-    if (lane == 0) for (int i = 0; i < 16; ++i) (ws + wl.js)[i] = (float)st_acc[i];
+    if (lane == 0) for (int i = 0; i < 24; ++i) (ws + wl.js)[i] = (float)st_acc[i];
 #endif
     if (lane == 0) {
         flag[0] = finished ? 1 : 0;

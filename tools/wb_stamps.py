@@ -14,7 +14,7 @@ for _ in range(3):
     s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"], t["U"], shift=1)
 torch.cuda.synchronize()
 L = s.debug_wb_layout()
-acc = np.stack([s.debug_workspace(b, L['js'], 16) for b in range(0, B, max(1, B // 32))])
+acc = np.stack([s.debug_workspace(b, L['js'], 24) for b in range(0, B, max(1, B // 32))])
 m = acc.mean(0)
 names = ["P+/K + prefetch", "synthesis", "PA, PB", "Hux, Huu -> LDS", "H -> LDS", "LDL", "H', W -> tiles", "Y = W Hux", "(last stage tail)",
          "forward sweeps", "IPM updates", "step + write-back", "prologue Q~ = Js'Js"]
@@ -22,4 +22,5 @@ tot = m[:13].sum()
 print(f"B={B}: {tot:.0f} cycles per wave and solve call; per backward stage {m[:8].sum() / 180:.0f}")
 for n, v in zip(names, m):
     print(f"  {n:22s} {v:12.0f}  {100 * v / tot:5.1f} %   per stage {v / 180:8.0f}")
+print(f"  tail of the backward stage (slots 16-18; slot 0 then holds the loop top only): P+ products {m[16] / 180:.0f}, mirror {m[17] / 180:.0f}, K products + stores {m[18] / 180:.0f}, loop top {m[0] / 180:.0f} per stage")
 print(f"  forward stage split (separate slots, not in the table's 'forward sweeps'): du = K dx {m[13] / 180:.0f}, dx+ {m[14] / 180:.0f}, hand-over {m[15] / 180:.0f} per stage")
