@@ -267,10 +267,12 @@ def timed_steps(setup, steps, warmup, dist=None, exchange=None, ramp=0.25):
             exchange(timed)
     # a fresh box starts at idle clocks: keep the device busy for a quarter of a second before the W warm-up
     # steps, so that the K timed steps measure the steady state whatever W is (setup, not part of W or K)
+    # (the solve alone, no exchange: a time-bounded loop runs a different number of passes on every rank, and a collective
+    #  inside it would be called a different number of times -- a deadlock that shows once the ranks' speeds differ)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < ramp:
         for _ in range(20 if not setup.wbm else 2):
-            step(False)
+            setup.solve(1)
         torch.cuda.synchronize()
     for _ in range(warmup):
         step(False)
