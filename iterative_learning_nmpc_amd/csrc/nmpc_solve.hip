@@ -843,9 +843,14 @@ void nmpc_qp_kernel(const SolveArgs a) {
                     // rotation at the end of this stage -- by then only this stage's K~/Acl~ stores are
                     // younger (vmcnt retires in order), so neither the loads nor the stores stall the sweep
                     const int kn = (k > 0) ? k - 1 : 0;
-                    const f32x4 A1 = il.load_A(At + (size_t)kn * G::A_FLOATS);
-                    const f32x4 B1 = il.load_B(Bt + (size_t)kn * G::B_FLOATS);
-                    const f32x4 T1 = il.load_Bt(Bt + (size_t)kn * G::B_FLOATS);
+#ifdef QP_T_ONEIMG      // timing build (tools/qp_traffic_timing.sh): every stage reads the images of stage 0 (cache-resident) -- results are wrong
+                    const int ki = (a.B < 0) ? kn : 0;
+#else
+                    const int ki = kn;
+#endif
+                    const f32x4 A1 = il.load_A(At + (size_t)ki * G::A_FLOATS);
+                    const f32x4 B1 = il.load_B(Bt + (size_t)ki * G::B_FLOATS);
+                    const f32x4 T1 = il.load_Bt(Bt + (size_t)ki * G::B_FLOATS);
                     // (read through an offset the compiler cannot see is uniform: the value stays in a
                     // VGPR until the end of the stage instead of being scalarised, and waited for, here)
                     const unsigned cm_next = umask[kn + lane_zero];
@@ -893,8 +898,13 @@ void nmpc_qp_kernel(const SolveArgs a) {
 #undef NMPC_COMMON
 #undef NMPC_RUN_COMMON
                     qp_ok = ok && qp_ok;
+#ifdef QP_T_NOSTORE     // timing build: no gain stores -- results are wrong, the time tells what the stores cost
+                    if (a.B < 0)
+#endif
+                    {
                     ks.store(Kt, Kk);      // gain tiles of this stage, read by the forward sweep
                     cs.store(Ct, Acl);
+                    }
                     A0 = il.fix_A(A1, lane);
                     B0 = il.fix_B(B1, lane);
                     T0 = il.fix_Bt(T1, lane);
@@ -963,7 +973,11 @@ void nmpc_qp_kernel(const SolveArgs a) {
                     asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ac) : "s"(vs[i]), "v"(e));
                 }
                 acc = (acc + acc1) + (acc2 + acc3);
+#ifdef QP_T_ONEIMG
+                load_row((a.B < 0) ? rowoff : rowlast, slot);
+#else
                 load_row(rowoff < rowlast ? rowoff : rowlast, slot);
+#endif
                 rowoff += rowstep;
                 dst[k * dstep] = acc;
 #pragma unroll

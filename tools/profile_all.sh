@@ -4,10 +4,10 @@
 set -uo pipefail
 tag="${1:-r02}"
 export TMPDIR=/tmp
-bash tools/profile.sh ${tag}_c
-bash tools/profile.sh ${tag}_c8k --batch 8192
+bash tools/profile.sh ${tag}_c; echo "headline done"
+bash tools/profile.sh ${tag}_c8k --batch 8192; echo "c8k done"
 bash tools/profile.sh ${tag}_wb --workload wholebody --steps 5 --warmup 1
-bash tools/profile.sh ${tag}_wbp1 --workload wholebody --precision 1 --steps 5 --warmup 1
+bash tools/profile.sh ${tag}_wbp3 --workload wholebody --precision 3 --steps 5 --warmup 1
 mkdir -p gpurun_out/prof_${tag}_roll
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_roll/kt -- python3 bench.py --rollouts 1024 --steps 3 --warmup 1 > gpurun_out/prof_${tag}_roll/kt.json 2> gpurun_out/prof_${tag}_roll/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_roll/kt -- python3 bench.py --rollouts 8192 --steps 2 --warmup 1 > gpurun_out/prof_${tag}_roll/kt.json 2> gpurun_out/prof_${tag}_roll/kt.err
 echo done
