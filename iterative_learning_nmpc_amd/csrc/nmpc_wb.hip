@@ -20,6 +20,7 @@
 // Stage data that does not fit the LDS (Q~, K~ images, 9 + 6 KB per stage) streams through an HBM workspace;
 // the per-stage record, the elimination columns and the transposition buffer live in the LDS (31 KB at N = 30).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "../../include/nmpc.h"
 #include "nmpc_wb_model.hpp"
@@ -102,6 +103,9 @@ struct WsLayout {
         arr = o; o += StageArr(N).total;
         flag = o; o += 4;
         stride = (o + 63) & ~(size_t)63;
+#ifdef WB_T_ODD_STRIDE       // timing build: an odd number of 256 B units per problem (do the problems' images camp on memory channels?)
+        if (((stride / 64) & 1) == 0) stride += 64;
+#endif
     }
 };
 
@@ -479,6 +483,153 @@ __device__ __forceinline__ void ldl_pivots(float (&X)[NU], bool& ok, const float
     }
 }
 
+// ---- the same elimination with its rank-1 updates on the matrix pipe ------------------------------------------------------
+// Register file: row i of [Huu | I] in register i & 3 of Xq[i >> 2] (lane = column).  v_mfma_f32_4x4x1_16b_f32 is sixteen 4 x 4
+// outer products, D[v][lane] = C[v][lane] + A[lane 4 (lane / 4) + v] B[lane], and with its A-broadcast control (cbsz = 4,
+// abid = g) all sixteen blocks take the A operand of block g: D[v][lane] = C[v][lane] + A[lane 4g + v] B[lane].  Huu is symmetric
+// and stays so under the elimination, so the multiplier of row i under pivot J, M[i][J], is what the scaled pivot row y_J holds
+// in LANE i: with A = y_J and B = -y_J ONE two-pass instruction updates the four rows of group g in all 64 columns -- no
+// broadcast, no data movement -- where the scalar form spends four v_readlane and four v_fma.
+// The pivots themselves are a dependent chain (v_readlane -> v_rsq -> scale -> update of the next row -> v_readlane ...): a pivot
+// updates the rows up to the end of panel P + LDL_AHEAD with scalar multipliers (v_readlane of y_J), the row groups further down
+// take the four pivots of a panel as four MFMAs each (tools/probes/mfma4x4x1.hip checks the operand layout on the device).
+constexpr int LDL_ROWS = 32, LDL_GROUPS = LDL_ROWS / 4;
+#ifndef WB_LDL_AHEAD
+#define WB_LDL_AHEAD 0
+#endif
+constexpr int LDL_AHEAD = WB_LDL_AHEAD;
+template <int J>
+__device__ __forceinline__ void bcast_lanes7(float y, float (&o)[7]) {
+    int r0, r1, r2, r3, r4, r5, r6;
+    // leading s_nop: see bcast_group
+    asm volatile("s_nop 0\n\tv_readlane_b32 %0, %7, %8\n\tv_readlane_b32 %1, %7, %9\n\tv_readlane_b32 %2, %7, %10\n\t"
+                 "v_readlane_b32 %3, %7, %11\n\tv_readlane_b32 %4, %7, %12\n\tv_readlane_b32 %5, %7, %13\n\t"
+                 "v_readlane_b32 %6, %7, %14\n\ts_nop 1"
+                 : "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3), "=s"(r4), "=s"(r5), "=s"(r6)
+                 : "v"(y), "n"(J + 1), "n"(J + 2), "n"(J + 3), "n"(J + 4), "n"(J + 5), "n"(J + 6), "n"(J + 7));
+    o[0] = __int_as_float(r0); o[1] = __int_as_float(r1); o[2] = __int_as_float(r2); o[3] = __int_as_float(r3);
+    o[4] = __int_as_float(r4); o[5] = __int_as_float(r5); o[6] = __int_as_float(r6);
+}
+template <int J>
+__device__ __forceinline__ void bcast_lanes3(float y, float (&o)[7]) {
+    int r0, r1, r2;
+    asm volatile("s_nop 0\n\tv_readlane_b32 %0, %3, %4\n\tv_readlane_b32 %1, %3, %5\n\tv_readlane_b32 %2, %3, %6\n\ts_nop 1"
+                 : "=s"(r0), "=s"(r1), "=s"(r2)
+                 : "v"(y), "n"(J + 1), "n"(J + 2), "n"(J + 3));
+    o[0] = __int_as_float(r0); o[1] = __int_as_float(r1); o[2] = __int_as_float(r2);
+    o[3] = o[4] = o[5] = o[6] = 0.0f;
+}
+// the pivots `panel` (bit jj: pivot 4P + jj is coupled) applied to the row groups G .. LDL_GROUPS-1
+template <int P, int G, unsigned MASK>
+__device__ __forceinline__ void ldl_trailing(f32x4 (&Xq)[LDL_GROUPS], const float (&ny)[4]) {
+    if constexpr (G < LDL_GROUPS) {
+        if constexpr (((MASK >> (4 * G)) & 0xFu) != 0u) {      // not a group of decoupled inputs only (or past the last row)
+            constexpr unsigned panel = (MASK >> (4 * P)) & 0xFu;
+            if constexpr (panel & 1u) Xq[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(Xq[P][0], ny[0], Xq[G], 4, G, 0);
+            if constexpr (panel & 2u) Xq[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(Xq[P][1], ny[1], Xq[G], 4, G, 0);
+            if constexpr (panel & 4u) Xq[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(Xq[P][2], ny[2], Xq[G], 4, G, 0);
+            if constexpr (panel & 8u) Xq[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(Xq[P][3], ny[3], Xq[G], 4, G, 0);
+        }
+        ldl_trailing<P, G + 1, MASK>(Xq, ny);
+    }
+}
+#ifdef WB_T_LDL_ROWCHAIN   // timing build (tools/ab_wb.sh): the panel's pivots as a chain of row operations
+template <int P, unsigned MASK>
+__device__ __forceinline__ void ldl_panel(f32x4 (&Xq)[LDL_GROUPS], bool& ok, const float (&rs_free)[12]) {
+    if constexpr (P < LDL_GROUPS) {
+        float ny[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto pivot = [&](auto jc) {
+            constexpr int J = 4 * P + decltype(jc)::value;
+            if constexpr (J < NU) {
+                if constexpr ((MASK >> J) & 1u) {
+                    const float d = bcast(Xq[P][J & 3], J);
+                    ok = ok && (d > 0.0f);
+                    const float y = Xq[P][J & 3] * __builtin_amdgcn_rsqf(d);
+                    Xq[P][J & 3] = y;
+                    ny[J & 3] = -y;
+                    constexpr int end = 4 * (P + LDL_AHEAD) + 3;
+                    constexpr int last = end < NU - 1 ? end : NU - 1;                    // last row that takes scalar multipliers
+                    constexpr unsigned below = (last > J) ? (MASK >> (J + 1)) & ((1u << (last - J)) - 1u) : 0u;
+                    if constexpr (below != 0u) {
+                        float l[7];
+                        if constexpr (last - J > 3) bcast_lanes7<J>(y, l); else bcast_lanes3<J>(y, l);
+#pragma unroll
+                        for (int u = 0; u < 7; ++u)
+                            if (u < last - J && ((below >> u) & 1u)) {
+                                const int i = J + 1 + u;
+                                Xq[i >> 2][i & 3] = fmaf(-l[u], y, Xq[i >> 2][i & 3]);
+                            }
+                    }
+                } else {
+                    Xq[P][J & 3] *= rs_free[J >= WF ? J - WF : 0];
+                }
+            }
+        };
+        pivot(std::integral_constant<int, 0>{});
+        pivot(std::integral_constant<int, 1>{});
+        pivot(std::integral_constant<int, 2>{});
+        pivot(std::integral_constant<int, 3>{});
+        ldl_trailing<P, P + 1 + LDL_AHEAD, MASK>(Xq, ny);
+        ldl_panel<P + 1, MASK>(Xq, ok, rs_free);
+    }
+}
+#else
+// One panel: the 4 x 4 diagonal block of the panel's rows (ten numbers, lanes 4P .. 4P+3 of the four registers) is factorised on
+// wave-uniform values -- pivot -> v_rsq -> multiplier -> next pivot, three operations per pivot and no cross-lane move on the
+// chain -- and the four rows follow it as y_c = (x_c - sum_{k<c} l_ck y_k) / sqrt(d_c); then the row groups below, on the matrix pipe.
+template <int P, unsigned MASK>
+__device__ __forceinline__ void ldl_panel(f32x4 (&Xq)[LDL_GROUPS], bool& ok, const float (&rs_free)[12]) {
+    if constexpr (P < LDL_GROUPS) {
+        constexpr int J0 = 4 * P;
+        constexpr unsigned pm = (MASK >> J0) & 0xFu;          // coupled rows of the panel (rows past NU - 1 have no bit)
+        float blk[4][4], l[4][4], rs[4] = {1.0f, 1.0f, 1.0f, 1.0f}, ny[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c)
+                blk[r][c] = (((pm >> r) & 1u) && ((pm >> c) & 1u)) ? bcast(Xq[P][r], J0 + c) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((pm >> c) & 1u) {
+                float d = blk[c][c];
+#pragma unroll
+                for (int k = 0; k < c; ++k)
+                    if ((pm >> k) & 1u) d = fmaf(-l[c][k], l[c][k], d);
+                ok = ok && (d > 0.0f);
+                rs[c] = __builtin_amdgcn_rsqf(d);
+#pragma unroll
+                for (int r = c + 1; r < 4; ++r)
+                    if ((pm >> r) & 1u) {
+                        float t = blk[r][c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k)
+                            if ((pm >> k) & 1u) t = fmaf(-l[r][k], l[c][k], t);
+                        l[r][c] = t * rs[c];
+                    }
+            } else if (J0 + c < NU) {
+                // a decoupled input (a force component of a swing foot): see ldl_pivots
+                rs[c] = rs_free[J0 + c >= WF ? J0 + c - WF : 0];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (J0 + c < NU) {
+                float v = Xq[P][c];
+                if ((pm >> c) & 1u) {
+#pragma unroll
+                    for (int k = 0; k < c; ++k)
+                        if ((pm >> k) & 1u) v = fmaf(-l[c][k], Xq[P][k], v);
+                }
+                v *= rs[c];
+                Xq[P][c] = v;
+                ny[c] = -v;
+            }
+        ldl_trailing<P, P + 1, MASK>(Xq, ny);
+        ldl_panel<P + 1, MASK>(Xq, ok, rs_free);
+    }
+}
+#endif
+
 // a lane shift inside the 16-lane rows (DPP row_shr:n = 0x110 + n: lane i reads lane i - n; row_shl:n = 0x100 + n: lane i + n);
 // lanes whose source falls outside their row read 0
 template <int CTRL>
@@ -625,6 +776,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
+                    if (j > i && !term) continue;      // the sweep reads the lower tiles of a running node, all nine of the terminal one
                     f32x4 acc = zero4();
 #pragma unroll
                     for (int t = 0; t < JT; ++t) acc = xty(J[t][i], J[t][j], acc);
@@ -635,6 +787,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
+                    if (j > i && !term) continue;      // the sweep reads the lower tiles of a running node, all nine of the terminal one
                     f32x4 acc = zero4();
 #pragma unroll
                     for (int t = 0; t < JT; ++t) {
@@ -655,6 +808,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int i = 0; i < XT; ++i)
 #pragma unroll
                 for (int j = 0; j < XT; ++j) {
+                    if (j > i && !term) continue;      // the sweep reads the lower tiles of a running node, all nine of the terminal one
                     f32x4 acc = zero4();
 #pragma unroll
                     for (int t = 0; t < JT; ++t) {
@@ -1064,26 +1218,26 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             // multiplier; the right-hand side H~ux is NOT carried through the elimination (the compiler split a second
             // column per lane into a pass of its own and parked all 435 multipliers in spilled SGPRs for it): Y = W H~ux
             // is formed on the matrix pipe below.
-            float Xc[NU];
+            f32x4 Xq[LDL_GROUPS];
             {
                 const bool is_h = lane < 32;
                 const float* pu = colU + (is_h ? lane : 0) * LDU;
 #pragma unroll
-                for (int i4 = 0; i4 < 8; ++i4) {
+                for (int i4 = 0; i4 < LDL_GROUPS; ++i4) {
                     const f32x4 vu = *reinterpret_cast<const f32x4*>(pu + 4 * i4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * i4 + r;
-                        if (i < NU) Xc[i] = is_h ? vu[r] : ((lane - 32 == i) ? 1.0f : 0.0f);
+                        Xq[i4][r] = (i < NU) ? (is_h ? vu[r] : ((lane - 32 == i) ? 1.0f : 0.0f)) : 0.0f;
                     }
                 }
             }
             bool ok = true;
             {
-                if (pat == 0x9u) ldl_pivots<0, coupling_mask(0x9u)>(Xc, ok, rs_free);
-                else if (pat == 0x6u) ldl_pivots<0, coupling_mask(0x6u)>(Xc, ok, rs_free);
-                else if (pat == 0x0u) ldl_pivots<0, coupling_mask(0x0u)>(Xc, ok, rs_free);
-                else ldl_pivots<0, coupling_mask(0xFu)>(Xc, ok, rs_free);
+                if (pat == 0x9u) ldl_panel<0, coupling_mask(0x9u)>(Xq, ok, rs_free);
+                else if (pat == 0x6u) ldl_panel<0, coupling_mask(0x6u)>(Xq, ok, rs_free);
+                else if (pat == 0x0u) ldl_panel<0, coupling_mask(0x0u)>(Xq, ok, rs_free);
+                else ldl_panel<0, coupling_mask(0xFu)>(Xq, ok, rs_free);
             }
             qp_ok = qp_ok && ok;
 #pragma unroll
@@ -1111,7 +1265,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * i4 + r;
-                        vw[r] = (i < NU) ? Xc[i < NU ? i : 0] : 0.0f;
+                        vw[r] = (i < NU) ? Xq[i4][r] : 0.0f;
                     }
                     if (lane >= 32) *reinterpret_cast<f32x4*>(pw + 4 * i4) = vw;
                 }
@@ -1192,7 +1346,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
                         for (int i = 0; i <= kk; ++i)                                   // W is lower triangular
 #pragma unroll
-                            for (int j = 0; j < XT; ++j) Kt[i][j] = mfma4(Wt[kk][i][st], nY[kk][j][st], Kt[i][j]);
+                            for (int j = 0; j < XT; ++j) Kt[i][j] = mfma4(nY[kk][j][st], Wt[kk][i][st], Kt[i][j]);      // K~' tiles: states x inputs
 #pragma unroll
                 for (int i = 0; i < UT; ++i)
 #pragma unroll
@@ -1226,11 +1380,24 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         f32x4 rec_ahead = load_rec(1);                      // the record of stage k + 1 while stage k runs
         wave_sync();
         const int urow = lane < NU ? lane : 0;
-        const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15));
+        // the gain images hold K~' (states x inputs, column-major): row `urow` of K~ is one contiguous column per state tile,
+        // eleven 16 B loads per lane instead of 43 dwords (the CU's address path takes 16 cycles per wave-instruction)
+        const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15) * TS);
         auto load_krow = [&](int k, float (&row)[HX + 1]) {
             const float* Kk = Kimg + (size_t)(k < N ? k : N - 1) * KT_FLOATS + krow_off;
 #pragma unroll
-            for (int j = 0; j <= HX; ++j) row[j] = Kk[(j >> 4) * IMG + (j & 15) * TS];
+            for (int j4 = 0; j4 < 10; ++j4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Kk + (j4 >> 2) * IMG + 4 * (j4 & 3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row[4 * j4 + r] = v[r];
+            }
+            // elements 40 .. 42 as 8 + 4 bytes: a fourth, unused register of a 16 B load is free for reuse at once, and whatever is
+            // written to it next waits for the load to land (write after write) -- that wait sat in the middle of the NEXT stage,
+            // behind all the row loads issued before it (vmcnt retires in order), and undid the prefetch
+            const f32x2 v2 = *reinterpret_cast<const f32x2*>(Kk + 2 * IMG + 8);
+            row[40] = v2[0]; row[41] = v2[1];
+            row[42] = Kk[2 * IMG + 10];
+            static_assert(HX == 42, "row tail");
         };
         const int fi = lane < NX ? lane : 0;
         const int hr = (fi >= 39) ? fi - 39 : 0, lr = (fi >= 36 && fi < 39) ? fi - 36 : 0;

@@ -6,6 +6,10 @@ import os, re, subprocess
 
 src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "iterative_learning_nmpc_amd", "csrc")
 print("# Kernel resources (hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form, -Rpass-analysis=kernel-resource-usage)\n")
+print("(the dispatch records of rocprofv3 show other numbers for the same kernels -- `VGPR_Count` 132 / 128 / 256, `Accum_VGPR_Count` 0: it decodes the\n"
+      "kernel descriptor's granulated register count with a granule of 4 where gfx90a+ has 8 for the unified file, i.e. it shows half of\n"
+      "`.amdhsa_next_free_vgpr` rounded up to 8 -- 257 -> 132, 256 -> 128, 512 -> 256 -- and does not decode the accumulation registers.  This table is\n"
+      "the compiler's.)\n")
 print("| kernel | VGPRs | AGPRs | SGPRs | SGPR spills | VGPR spills | scratch B/lane | waves/SIMD |")
 print("|---|---|---|---|---|---|---|---|")
 for f in ("nmpc_api.hip", "nmpc_policy.hip", "nmpc_dataset.hip", "nmpc_torque.hip"):

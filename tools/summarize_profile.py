@@ -29,7 +29,12 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
             meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
 if vals:
     out += [f"## PMC counters of `{kname}` (mean per dispatch over {max(len(v) for v in vals.values())} dispatches)", "",
-            f"dispatch: {json.dumps(meta)}", "", "| counter | mean per dispatch |", "|---|---|"]
+            f"dispatch: {json.dumps(meta)}", "",
+            "(rocprofv3's `VGPR_Count` is (granulated_workitem_vgpr_count + 1) x 4 of the kernel descriptor: on gfx90a+ the granule of the "
+            "unified register file is 8, so the figure is HALF the allocated arch + accumulation registers -- 132 for `.amdhsa_next_free_vgpr 257` "
+            "(264 allocated), 128 for 256, 256 for 512 -- and `Accum_VGPR_Count` is not decoded (always 0).  The compiler's own figures are in "
+            "profiles/*_isa_resources.md: 231 + 0, 256 + 0, 256 + 255.)", "",
+            "| counter | mean per dispatch |", "|---|---|"]
     for k in sorted(vals):
         out.append(f"| {k} | {sum(vals[k]) / len(vals[k]):.4g} |")
     m = {k: sum(v) / len(v) for k, v in vals.items()}
