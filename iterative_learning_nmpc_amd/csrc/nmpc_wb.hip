@@ -392,15 +392,13 @@ constexpr int IPMW = 57;     // LDS row of a stage's barrier-modified input term
 constexpr int IPM_RF = 32;
 
 struct WbLds {
-    int colU, hbuf, recb, ipm, dxv, duv, total;
+    int colU, hbuf, recb, ipm, total;
     __host__ __device__ explicit WbLds(int N) {
         int o = 0;
         colU = o; o += NG * 0 + 32 * LDU;
         hbuf = o; o += 48 * LDH;
         recb = o; o += 256;
         ipm = o;  o += r4(N * IPMW);
-        dxv = o;  o += 48;
-        duv = o;  o += 32;
         total = o;
     }
 };
@@ -693,7 +691,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     float* sv = arr + SA.sv;   float* lv = arr + SA.lv;
     float* colU = smem + L.colU; float* hbuf = smem + L.hbuf;
     float* recb = smem + L.recb; float* ipm = smem + L.ipm;
-    float* dxv = smem + L.dxv;   float* duv = smem + L.duv;
     const float* recs = ws + wl.rec;
     float* Qimg = ws + wl.qt;
     float* Kimg = ws + wl.kt;
@@ -715,25 +712,38 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         qdiag[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, false) : 0.0f) + a.reg : 0.0f;
         qdiag_e[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, true) : 0.0f) + a.reg_e : 0.0f;
     }
-    for (int k = 0; k <= N; ++k) {
-        const bool term = (k == N);
+    // the Jacobian tiles and the gradient entries of node k + 1 are requested while node k is contracted (one node per
+    // iteration with its loads at the top waited a full memory latency per node: 6 k cycles for 1.5 k cycles of products)
+    f32x4 Jn[JT][XT], gcol_n[XT];
+    float grow_n[XT];
+    auto request_node = [&](int k) {
         const float* js = ws + wl.js + (size_t)k * JS_FLOATS;
         const float* rec = recs + (size_t)k * REC;
-        f32x4 J[JT][XT];
 #pragma unroll
         for (int t = 0; t < JT; ++t)
 #pragma unroll
-            for (int j = 0; j < XT; ++j) J[t][j] = load_tile(js + (t * XT + j) * IMG, lane);
+            for (int j = 0; j < XT; ++j) Jn[t][j] = load_tile(js + (t * XT + j) * IMG, lane);
         // gradient of the diagonal residuals: column HX (lanes c == 10 of tile column 2) and row HX
-        f32x4 gcol[XT];
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             const int row0 = 16 * i + 4 * q4;
-            gcol[i] = *reinterpret_cast<const f32x4*>(rec + R_GQ + (row0 < 36 ? row0 : 0));
+            gcol_n[i] = *reinterpret_cast<const f32x4*>(rec + R_GQ + (row0 < 36 ? row0 : 0));
         }
+#pragma unroll
+        for (int j = 0; j < XT; ++j) { const int col = 16 * j + c; grow_n[j] = rec[R_GQ + (col < 36 ? col : 0)]; }
+    };
+    request_node(0);
+    for (int k = 0; k <= N; ++k) {
+        const bool term = (k == N);
+        f32x4 J[JT][XT], gcol[XT];
         float grow[XT];
 #pragma unroll
-        for (int j = 0; j < XT; ++j) { const int col = 16 * j + c; grow[j] = rec[R_GQ + (col < 36 ? col : 0)]; }
+        for (int t = 0; t < JT; ++t)
+#pragma unroll
+            for (int j = 0; j < XT; ++j) J[t][j] = Jn[t][j];
+#pragma unroll
+        for (int i = 0; i < XT; ++i) { gcol[i] = gcol_n[i]; grow[i] = grow_n[i]; }
+        request_node(k < N ? k + 1 : N);
         // mixed precision (BASELINE configs[4]): the scaled Jacobian rounded to bf16 -- or split into a bf16 head and a
         // bf16 tail, J = hi + lo -- and contracted on the bf16 matrix pipe with fp32 accumulation
         // (v_mfma_f32_16x16x16_bf16: one instruction per 16 residual rows where fp32 takes four steps); the accumulator
@@ -994,8 +1004,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         for (int i = 0; i < XT; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)(N - 1) * QT_FLOATS + (i * XT + j) * IMG, lane);
+        WB_STAMP(21);          // terminal tiles, first record and Q~ tiles requested
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
+            WB_STAMP(19);      // the loop's back edge
             // prefetch: next record, this stage's Q~ tiles were requested ... (Q of stage k is loaded here; the
             // loads are issued first and consumed after the P~A~, P~B~ products)
             const f32x4 rec_next = rec_pref;
@@ -1514,14 +1526,37 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             mu_sum = wave_sum(m_l);
             // step <- step + ap (new step - step)
-            for (int i = lane; i < NX * NS; i += 64) { const float d = (ii == 0) ? 0.0f : dX[i]; dX[i] = d + ap * (dXp[i] - d); }
-            for (int i = lane; i < NU * NS; i += 64) { const float d = (ii == 0) ? 0.0f : dU[i]; dU[i] = d + ap * (dUp[i] - d); }
+            // [dX | dU] and [dXp | dUp] have the same layout (StageArr): one pass over both in 16 B pieces, five pieces per lane in
+            // flight.  (As two scalar loops -- load, blend, store, 36 trips -- this blend waited a full memory latency per trip:
+            // 66 k cycles per sweep, a seventh of the kernel, tools/wb_stamps.py slot 20.)
+            {
+                const int nvec = (SA.dXp - SA.dX) >> 2;
+                f32x4* d4 = reinterpret_cast<f32x4*>(dX);
+                const f32x4* n4 = reinterpret_cast<const f32x4*>(dXp);
+                constexpr int BL = 5;
+                for (int i0 = lane; i0 < nvec; i0 += 64 * BL) {
+                    f32x4 dv[BL], nv[BL];
+#pragma unroll
+                    for (int u = 0; u < BL; ++u) {
+                        const int i = i0 + 64 * u;
+                        const int ic = i < nvec ? i : i0;
+                        nv[u] = n4[ic];
+                        dv[u] = (ii == 0) ? zero4() : d4[ic];
+                    }
+#pragma unroll
+                    for (int u = 0; u < BL; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < nvec) d4[i] = dv[u] + ap * (nv[u] - dv[u]);
+                    }
+                }
+            }
             phase_sync();
             if (ii + 1 < n_sweeps) {
                 write_ipm_terms(fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min));
                 wave_sync();
             }
         }
+        WB_STAMP(20);      // interior-point update of this sweep
     }
     WB_STAMP(10);
     // ---------------------------------------------------------------- phase S: step
