@@ -864,26 +864,27 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     phase_sync();
 
     // barrier-modified input terms of stage `lane`, lane = stage: rt = r + G'(tau/s + lam + D c), Rf = G'DG per foot
-    auto write_ipm_terms = [&](float tau) {
+    // barrier-modified input terms of stage `lane` into its LDS row, from the stage's slacks, multipliers, constraint values and
+    // input gradient in registers
+    auto ipm_terms = [&](float tau, const float (&sj)[NG], const float (&lj)[NG], const float (&cj)[NG], const float (&rr)[NU]) {
         if (lane < N) {
-            const float* rec = recs + (size_t)lane * REC;
             float* row = ipm + lane * IPMW;
 #pragma unroll
-            for (int i = 0; i < WF; ++i) row[i] = rec[R_R + i];
+            for (int i = 0; i < WF; ++i) row[i] = rr[i];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 float D[4], v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool on = use_ipm && ((my_act >> (4 * f + j)) & 1u);
-                    const float s = AT(sv, lane, 4 * f + j), l = AT(lv, lane, 4 * f + j), cj = rec[R_C + 4 * f + j];
+                    const float s = sj[4 * f + j], l = lj[4 * f + j];
                     const float is = fast_rcp(s);
                     D[j] = on ? l * is : 0.0f;
-                    v[j] = on ? tau * is + l + l * is * cj : 0.0f;
+                    v[j] = on ? tau * is + l + l * is * cj[4 * f + j] : 0.0f;
                 }
-                row[WF + 3 * f + 0] = rec[R_R + WF + 3 * f + 0] + (v[0] - v[1]);
-                row[WF + 3 * f + 1] = rec[R_R + WF + 3 * f + 1] + (v[2] - v[3]);
-                row[WF + 3 * f + 2] = rec[R_R + WF + 3 * f + 2] - mp.mu * ((v[0] + v[1]) + (v[2] + v[3]));
+                row[WF + 3 * f + 0] = rr[WF + 3 * f + 0] + (v[0] - v[1]);
+                row[WF + 3 * f + 1] = rr[WF + 3 * f + 1] + (v[2] - v[3]);
+                row[WF + 3 * f + 2] = rr[WF + 3 * f + 2] - mp.mu * ((v[0] + v[1]) + (v[2] + v[3]));
                 row[IPM_RF + 5 * f + 0] = D[0] + D[1];
                 row[IPM_RF + 5 * f + 1] = D[2] + D[3];
                 row[IPM_RF + 5 * f + 2] = mp.mu * mp.mu * ((D[0] + D[1]) + (D[2] + D[3]));
@@ -891,6 +892,16 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 row[IPM_RF + 5 * f + 4] = -mp.mu * (D[2] - D[3]);
             }
         }
+    };
+    auto write_ipm_terms = [&](float tau) {      // the same from memory (first sweep)
+        const int kl = lane < N ? lane : 0;
+        const float* rec = recs + (size_t)kl * REC;
+        float sj[NG], lj[NG], cj[NG], rr[NU];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { sj[j] = AT(sv, kl, j); lj[j] = AT(lv, kl, j); cj[j] = rec[R_C + j]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rr[i] = rec[R_R + i];
+        ipm_terms(tau, sj, lj, cj, rr);
     };
 
     // per-lane constants of the tile synthesis: every element of N~ = A~ - I, B~, R~ and S~ is ONE LDS read at a
@@ -977,33 +988,37 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
 
     bool qp_ok = true;
-    for (int ii = 0; ii < n_sweeps; ++ii) {
-        const float tau = use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f;
-        if (ii == 0) { write_ipm_terms(tau); wave_sync(); }
-        // ------------------------------------------------------------ phase R: backward sweep
-        f32x4 P[XT][XT];
+    // What a backward sweep starts from -- terminal P~ (nine tiles), the records of stages N-1 and N-2, the lower Q~ tiles of stage
+    // N-1 -- is the same for every sweep of a call and is requested at the top of the interior-point phase BEFORE it, so that the
+    // sweep does not open with a memory latency.
+    f32x4 P[XT][XT], Qn[XT][XT], rec_first, rec_pref;
+    auto request_sweep = [&]() {
 #pragma unroll
         for (int i = 0; i < XT; ++i)
 #pragma unroll
             for (int j = 0; j < XT; ++j) P[i][j] = load_tile(Qimg + (size_t)N * QT_FLOATS + (i * XT + j) * IMG, lane);
-        // record of stage N-1 into the LDS; each stage prefetches the next one's (global -> registers -> LDS)
-        {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(recs + (size_t)(N - 1) * REC + (4 * lane < REC ? 4 * lane : 0));
-            *reinterpret_cast<f32x4*>(recb + 4 * lane) = v;
-        }
-        // The record of stage k-1 is requested in the middle of stage k+1, next to the Q~ tiles -- BEFORE that stage's K~ stores.
-        // vmcnt retires in order: requested at the top of stage k (behind the six K~ stores of stage k+1), waiting for it meant
-        // waiting for those stores to reach memory, every stage (s_waitcnt vmcnt(0) in the middle of the stage).
-        f32x4 rec_pref = *reinterpret_cast<const f32x4*>(recs + (size_t)(N > 1 ? N - 2 : 0) * REC + (4 * lane < REC ? 4 * lane : 0));
-        wave_sync();
-        // Q~ tiles (lower ones) are requested one and a half stages ahead of their use: for stage k-1 in the middle of
-        // stage k.  (A timing build that reads one cache-resident image instead of each stage's own ran 10 % faster:
-        // requested at the top of their own stage, the 6 KB did not arrive by the time H needs them.)
-        f32x4 Qn[XT][XT];
+        rec_first = *reinterpret_cast<const f32x4*>(recs + (size_t)(N - 1) * REC + (4 * lane < REC ? 4 * lane : 0));
+        rec_pref = *reinterpret_cast<const f32x4*>(recs + (size_t)(N > 1 ? N - 2 : 0) * REC + (4 * lane < REC ? 4 * lane : 0));
 #pragma unroll
         for (int i = 0; i < XT; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)(N - 1) * QT_FLOATS + (i * XT + j) * IMG, lane);
+    };
+    request_sweep();
+    for (int ii = 0; ii < n_sweeps; ++ii) {
+        const float tau = use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f;
+        if (ii == 0) { write_ipm_terms(tau); wave_sync(); }
+        // ------------------------------------------------------------ phase R: backward sweep
+        // (terminal P~, the records of stages N-1 and N-2 and the Q~ tiles of stage N-1 were requested by request_sweep())
+        // record of stage N-1 into the LDS; each stage prefetches the next one's (global -> registers -> LDS)
+        *reinterpret_cast<f32x4*>(recb + 4 * lane) = rec_first;
+        // The record of stage k-1 is requested in the middle of stage k+1, next to the Q~ tiles -- BEFORE that stage's K~ stores.
+        // vmcnt retires in order: requested at the top of stage k (behind the six K~ stores of stage k+1), waiting for it meant
+        // waiting for those stores to reach memory, every stage (s_waitcnt vmcnt(0) in the middle of the stage).
+        wave_sync();
+        // Q~ tiles (lower ones) are requested one and a half stages ahead of their use: for stage k-1 in the middle of
+        // stage k.  (A timing build that reads one cache-resident image instead of each stage's own ran 10 % faster:
+        // requested at the top of their own stage, the 6 KB did not arrive by the time H needs them.)
         WB_STAMP(21);          // terminal tiles, first record and Q~ tiles requested
         for (int k = N - 1; k >= 0; --k) {
             const int kn = k > 0 ? k - 1 : 0;
@@ -1492,25 +1507,51 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         phase_sync();
         WB_STAMP(9);
         // ------------------------------------------------------------ phase I: interior-point update, lane = stage
+        // Everything the phase reads from memory is requested in one go at its top -- its own inputs, the first pieces of the
+        // step blend, the input gradient of the next sweep's barrier terms -- and nothing in it waits for a store: written
+        // serially (load, compute, store, fence, load ...) the phase took six memory latencies per sweep, 15 % of the kernel
+        // (tools/wb_stamps.py, slot 20).  Addresses are uniform base + lane offset (one VGPR for all of them).
         if (use_ipm) {
+            const bool more = ii + 1 < n_sweeps;
             const bool live = lane < N;
             const int k = live ? lane : 0;
+            const unsigned k4 = 4u * (unsigned)k;
             const float* rec = recs + (size_t)k * REC;
-            float duf[12], g[NG], s[NG], l[NG], ds[NG], dl[NG], cc[NG];
+            float duf[12], g[NG], s[NG], l[NG], cc[NG], rr[NU];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) duf[i] = AT(dUp, k, WF + i);
+            for (int i = 0; i < 12; ++i) duf[i] = ld_f32(dUp + (WF + i) * NS, k4, 0);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { cc[j] = rec[R_C + j]; s[j] = ld_f32(sv + j * NS, k4, 0); l[j] = ld_f32(lv + j * NS, k4, 0); }
+            // step <- step + ap (new step - step): [dX | dU] and [dXp | dUp] have the same layout (StageArr), one pass over both
+            // in 16 B pieces, five pieces per lane in flight
+            const int nvec = (SA.dXp - SA.dX) >> 2;
+            f32x4* d4 = reinterpret_cast<f32x4*>(dX);
+            const f32x4* n4 = reinterpret_cast<const f32x4*>(dXp);
+            constexpr int BL = 5;
+            f32x4 dv[BL], nv[BL];
+            auto blend_request = [&](int i0) {
+#pragma unroll
+                for (int u = 0; u < BL; ++u) {
+                    const int i = i0 + 64 * u;
+                    const int ic = i < nvec ? i : i0;
+                    nv[u] = n4[ic];
+                    dv[u] = (ii == 0) ? zero4() : d4[ic];
+                }
+            };
+            blend_request(lane);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) rr[i] = more ? rec[R_R + i] : 0.0f;
             gdot(mp, duf, g);
+            // (the steps ds, dl are formed twice -- for the step lengths and for the update -- rather than kept: 32 registers)
             float rp = 0.0f, rd = 0.0f;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
-                cc[j] = rec[R_C + j];
-                s[j] = AT(sv, k, j); l[j] = AT(lv, k, j);
                 const float is = fast_rcp(s[j]);
-                ds[j] = -(g[j] + cc[j]) - s[j];
-                dl[j] = tau * is - l[j] - l[j] * is * ds[j];
+                const float dsj = -(g[j] + cc[j]) - s[j];
+                const float dlj = tau * is - l[j] - l[j] * is * dsj;
                 const bool on = live && ((my_act >> j) & 1u);
-                rp = on ? fmaxf(rp, -ds[j] * is) : rp;
-                rd = on ? fmaxf(rd, -dl[j] * __builtin_amdgcn_rcpf(l[j])) : rd;
+                rp = on ? fmaxf(rp, -dsj * is) : rp;
+                rd = on ? fmaxf(rd, -dlj * __builtin_amdgcn_rcpf(l[j])) : rd;
             }
             const float rpm = wave_max(rp), rdm = wave_max(rd);
             const float ap = rpm > a.gamma ? a.gamma / rpm : 1.0f;
@@ -1518,47 +1559,41 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             float m_l = 0.0f;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
+                const float is = fast_rcp(s[j]);
+                const float dsj = -(g[j] + cc[j]) - s[j];
+                const float dlj = tau * is - l[j] - l[j] * is * dsj;
                 const bool on = live && ((my_act >> j) & 1u);
-                s[j] += on ? ap * ds[j] : 0.0f;
-                l[j] += on ? ad * dl[j] : 0.0f;
-                if (live) { AT(sv, k, j) = s[j]; AT(lv, k, j) = l[j]; }
+                s[j] += on ? ap * dsj : 0.0f;
+                l[j] += on ? ad * dlj : 0.0f;
                 m_l += on ? s[j] * l[j] : 0.0f;
             }
-            mu_sum = wave_sum(m_l);
-            // step <- step + ap (new step - step)
-            // [dX | dU] and [dXp | dUp] have the same layout (StageArr): one pass over both in 16 B pieces, five pieces per lane in
-            // flight.  (As two scalar loops -- load, blend, store, 36 trips -- this blend waited a full memory latency per trip:
-            // 66 k cycles per sweep, a seventh of the kernel, tools/wb_stamps.py slot 20.)
-            {
-                const int nvec = (SA.dXp - SA.dX) >> 2;
-                f32x4* d4 = reinterpret_cast<f32x4*>(dX);
-                const f32x4* n4 = reinterpret_cast<const f32x4*>(dXp);
-                constexpr int BL = 5;
-                for (int i0 = lane; i0 < nvec; i0 += 64 * BL) {
-                    f32x4 dv[BL], nv[BL];
+            if (live) {
 #pragma unroll
-                    for (int u = 0; u < BL; ++u) {
-                        const int i = i0 + 64 * u;
-                        const int ic = i < nvec ? i : i0;
-                        nv[u] = n4[ic];
-                        dv[u] = (ii == 0) ? zero4() : d4[ic];
-                    }
-#pragma unroll
-                    for (int u = 0; u < BL; ++u) {
-                        const int i = i0 + 64 * u;
-                        if (i < nvec) d4[i] = dv[u] + ap * (nv[u] - dv[u]);
-                    }
-                }
+                for (int j = 0; j < NG; ++j) { st_f32(sv + j * NS, k4, 0, s[j]); st_f32(lv + j * NS, k4, 0, l[j]); }
             }
-            phase_sync();
-            if (ii + 1 < n_sweeps) {
-                write_ipm_terms(fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min));
+            mu_sum = wave_sum(m_l);
+            for (int i0 = lane; i0 < nvec; i0 += 64 * BL) {
+#pragma unroll
+                for (int u = 0; u < BL; ++u) {
+                    const int i = i0 + 64 * u;
+                    if (i < nvec) d4[i] = dv[u] + ap * (nv[u] - dv[u]);
+                }
+                if (i0 + 64 * BL < nvec) blend_request(i0 + 64 * BL);
+            }
+            // (no fence here: the next reader of dX, dU across lanes is the step phase, behind its own phase_sync; the slacks and
+            //  multipliers are read back by the lane that wrote them)
+            request_sweep();      // (unconditionally: defined on every path round the loop, it holds no register through the other phases)
+            if (more) {
+                ipm_terms(fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min), s, l, cc, rr);
                 wave_sync();
             }
+        } else {
+            request_sweep();
         }
         WB_STAMP(20);      // interior-point update of this sweep
     }
     WB_STAMP(10);
+    phase_sync();
     // ---------------------------------------------------------------- phase S: step
     float sn_l = 0.0f;
     bool bad_l = false;
