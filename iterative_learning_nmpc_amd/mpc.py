@@ -412,7 +412,8 @@ class BatchedLocomotionMPC:
             times = (times[:, None] + (np.arange(self.replanning_steps) + 1) * self.sim_dt).ravel()
         return S, times
 
-    def open_loop_device_valid(self, x0: np.ndarray, trajectory_time: float, push_sampler, nominal=(0,), max_attempts: int = 8):
+    def open_loop_device_valid(self, x0: np.ndarray, trajectory_time: float, push_sampler, nominal=(0,), max_attempts: int = 8,
+                               fill_batch: int = 0):
         """Pushed rollouts with the reference's discard-and-redo: a rollout that terminates early is thrown away and rolled
         again from the same initial state with a NEW push, until it runs to the end
         (data_collection_pretrain_omini_vc_policy_1direction_perturbed.py:217-247, `while True: ... if not
@@ -422,7 +423,11 @@ class BatchedLocomotionMPC:
         gets no sampling weight in the learning update (parallel.learning_update).
 
         push_sampler(n, attempt) -> {"start", "duration", "force": [n, 3]}; the rollouts listed in `nominal` are never
-        pushed (and never redone).  Call on a freshly reset controller.  Returns (S, t, info) with S, t as
+        pushed (and never redone).  `fill_batch` > 0: a redo pass over n rollouts rolls max(1, min(fill_batch, batch) // n) candidates
+        of each, every one with its own new push, and keeps the FIRST that runs to the end -- the same distribution as the
+        reference's one-after-the-other redo (independent pushes, first success kept), but the late passes over a
+        handful of rollouts, which take fifty replans each however small they are, collapse into one.
+        Call on a freshly reset controller.  Returns (S, t, info) with S, t as
         `open_loop_device` and info = {"attempt_sizes": rollouts run per attempt, "first_attempt": flag counts of the first
         pass}; `self.failed`, `self.x_final`, `self.X`, `self.U`, `self.foot_pos` hold the kept rollouts."""
         assert self.first_solve and self.current_opt_node == 0, "open_loop_device_valid starts from a reset controller"
@@ -449,25 +454,32 @@ class BatchedLocomotionMPC:
             n = int(idx.numel())                                   # (the one host round trip of an attempt)
             if n == 0:
                 break
-            idx_h = idx.cpu().numpy()
-            push_n = push_sampler(n, attempt)
+            cand = max(1, min(fill_batch, B) // n)                       # candidates per rollout of this pass (the solver holds B problems)
+            m = n * cand
+            idx_h = np.repeat(idx.cpu().numpy(), cand)                    # candidate j rolls rollout idx[j // cand]
+            push_n = push_sampler(m, attempt)
             x = s.to_device(x0[idx_h])
             v_des = torch.as_tensor(self.v_des[idx_h], dtype=torch.float64).to(dev).contiguous()
             w_des = torch.as_tensor(self.w_des[idx_h], dtype=torch.float64).to(dev).contiguous()
             ref_state = torch.as_tensor(ref0[idx_h], dtype=torch.float64).to(dev).contiguous()
-            foot = s.to_device(foot0[idx_h].reshape(n, 12))
-            Xn = torch.zeros(n, self.n_nodes + 1, 12, dtype=torch.float32, device=dev)
-            Un = torch.zeros(n, self.n_nodes, 12, dtype=torch.float32, device=dev)
-            stn = torch.zeros(n, dtype=torch.int32, device=dev)
+            foot = s.to_device(foot0[idx_h].reshape(m, 12))
+            Xn = torch.zeros(m, self.n_nodes + 1, 12, dtype=torch.float32, device=dev)
+            Un = torch.zeros(m, self.n_nodes, 12, dtype=torch.float32, device=dev)
+            stn = torch.zeros(m, dtype=torch.int32, device=dev)
             Sn, failed_n = self._device_rollout(n_replans, 0, True, push_n, x, v_des, w_des, ref_state, foot, Xn, Un, stn)
-            S[idx] = Sn
-            self.failed[idx] = failed_n
-            self.x_final[idx] = x
-            self.X[idx] = Xn; self.U[idx] = Un; self.status[idx] = stn
-            self.base_ref_vel_tracking[idx_h] = ref_state.cpu().numpy()
+            # the candidate kept for a rollout: its first valid one, or its first one if none is
+            bad = (failed_n & self.invalid_mask).ne(0).view(n, cand)
+            first_ok = torch.argmax((~bad).to(torch.int8), dim=1)         # (argmax of an all-zero row is 0)
+            pick = torch.arange(n, device=dev) * cand + first_ok
+            S[idx] = Sn[pick]
+            self.failed[idx] = failed_n[pick]
+            self.x_final[idx] = x[pick]
+            self.X[idx] = Xn[pick]; self.U[idx] = Un[pick]; self.status[idx] = stn[pick]
+            pick_h, rows_h = pick.cpu().numpy(), idx_h[::cand]
+            self.base_ref_vel_tracking[rows_h] = ref_state.cpu().numpy()[pick_h]
             if self.footsteps:
-                self.foot_pos[idx_h] = foot.cpu().numpy().astype(np.float64).reshape(n, 4, 3)
-            info["attempt_sizes"].append(n)
+                self.foot_pos[rows_h] = foot.cpu().numpy().astype(np.float64).reshape(m, 4, 3)[pick_h]
+            info["attempt_sizes"].append(m)
         return S, times, info
 
     def record_state(self, x: np.ndarray, t: float) -> np.ndarray:

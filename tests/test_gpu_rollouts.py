@@ -253,6 +253,46 @@ def test_discard_and_redo_of_failed_rollouts(dev):
     assert np.array_equal(Sn[redo[ok1]], S1.cpu().numpy()[ok1])
 
 
+def test_redo_with_several_candidates_keeps_the_first_valid_one(dev):
+    """fill_batch: a redo pass rolls fill_batch // n candidates of every discarded rollout, each with its own new push, and
+    keeps the first that runs to the end -- the reference's one-by-one redo, several tries at once.  The kept rollout is bit for
+    bit the rollout of that candidate's push alone."""
+    from iterative_learning_nmpc_amd.mpc import BatchedLocomotionMPC, TERM_SHIFT, sample_pushes
+    B, T, FILL = 512, 2.0, 512
+    x0 = np.zeros((B, 12)); x0[:, 2] = 0.3
+    x0[:, 0] = 0.01 * np.arange(B)                      # distinct initial states: a candidate must start from ITS rollout's
+    sampler = lambda n, attempt: sample_pushes(n, (11, attempt), start=0.2, duration=0.3)
+    mpc = BatchedLocomotionMPC(B, n_nodes=50, device=dev, footsteps=True)
+    mpc.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+    S, t, info = mpc.open_loop_device_valid(x0, T, sampler, nominal=(0,), max_attempts=12, fill_batch=FILL)
+    f = mpc.failed.cpu().numpy()
+    sizes = info["attempt_sizes"]
+    print("redo with candidates:", info)
+    n1 = info["first_attempt"]["invalid"]
+    cand = max(1, min(FILL, B) // n1)
+    assert n1 > 0 and cand >= 2 and sizes[1] == n1 * cand
+    assert ((f & mpc.invalid_mask) == 0).all() and (f >> TERM_SHIFT == 0).all()
+    Sn = S.cpu().numpy()
+    assert np.isfinite(Sn).all()
+    # replay: the first pass, then all candidates of pass 1 on their own
+    first = BatchedLocomotionMPC(B, n_nodes=50, device=dev, footsteps=True)
+    first.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+    p0 = sampler(B, 0); p0["force"][0] = 0.0
+    first.open_loop_device(x0, T, p0)
+    redo = np.nonzero((first.failed.cpu().numpy() & first.invalid_mask) != 0)[0]
+    assert len(redo) == n1
+    rows = np.repeat(redo, cand)
+    alone = BatchedLocomotionMPC(len(rows), n_nodes=50, device=dev, footsteps=True)
+    alone.set_command(np.array([0.3, 0.0, 0.0]), 0.0)
+    S1, _ = alone.open_loop_device(x0[rows], T, sampler(len(rows), 1))
+    ok = ((alone.failed.cpu().numpy() & alone.invalid_mask) == 0).reshape(n1, cand)
+    S1 = S1.cpu().numpy().reshape(n1, cand, *Sn.shape[1:])
+    settled = ok.any(axis=1)
+    assert settled.any()
+    firsts = np.argmax(ok, axis=1)
+    assert np.array_equal(Sn[redo[settled]], S1[settled, firsts[settled]])
+
+
 def test_solver_skip_mask(dev):
     """nmpc_set_skip: flagged problems are left out of a solve -- X, U, status untouched -- and the others do not notice"""
     from iterative_learning_nmpc_amd import workloads as wl
