@@ -444,3 +444,44 @@ def test_wholebody_device_rollouts_batch_and_termination(dev):
     small.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
     Ss = small.open_loop_device(q0[:n], v0[:n], T, push=dict(push, force=force[:n]), record_sim_steps=False)
     assert np.array_equal(Ss.cpu().numpy(), Sn[:n]) and np.array_equal(small.failed.cpu().numpy(), f[:n])
+
+
+def test_wholebody_device_rollouts_full_size(dev):
+    """BASELINE-sized: 8192 pushed whole-body rollouts of 2 s (50 replans) from one call per replan, no host round trip inside
+    a rollout.  Size-independent properties: finite rows, unit quaternions, no solver failure, terminated rollouts frozen below
+    the collision height, copies of one rollout anywhere in the batch bit for bit equal, the first 16 bit for bit what they are
+    in a batch of 16."""
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    B, T = 8192, 2.0
+    rng = np.random.default_rng(5)
+    q0 = np.zeros((B, 18)); q0[:, 2] = 0.30; q0[:, 6:] = wbk.Q_HOME + rng.normal(0, 0.03, (B, 12))
+    v0 = np.zeros((B, 18))
+    force = rng.uniform(-1, 1, (B, 3)); force /= np.linalg.norm(force, axis=1, keepdims=True); force *= rng.uniform(50, 70, (B, 1))
+    force[0] = 0.0
+    copies = np.array([1000, 4095, 4096, 8191])                  # rollout 7, again, in other waves / rounds of the launch
+    q0[copies], force[copies] = q0[7], force[7]
+    push = dict(start=0.2, duration=0.3, force=force)
+    mpc = LocomotionMPC(print_info=False, device=dev, batch=B, n_nodes=30, force_reference="gravity_share")
+    mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    S = mpc.open_loop_device(q0, v0, T, push=push, record_sim_steps=False)
+    torch.cuda.synchronize()
+    Sn, f = S.cpu().numpy(), mpc.failed.cpu().numpy()
+    assert Sn.shape[0] == B and Sn.shape[1] in (50, 51) and Sn.shape[2] == 44 and np.isfinite(Sn).all()
+    assert (f & 1 == 0).all(), np.nonzero(f & 1)[0][:10]                      # no solver failure
+    assert f[0] >> 8 == 0
+    assert np.allclose(np.linalg.norm(Sn[:, :, 20:24], axis=-1), 1.0, atol=1e-5)
+    term = np.nonzero(f >> 8)[0]
+    print(f"whole-body rollouts, full size: {len(term)} of {B} terminated early, flag counts",
+          {name: int((f & bit != 0).sum()) for name, bit in (("roll", 2), ("pitch", 4), ("height", 8), ("vel", 16), ("collision", 32), ("joint", 64))})
+    for b in term[:64]:
+        i = (f[b] >> 8) - 1
+        assert (Sn[b, i:] == Sn[b, i]).all() and Sn[b, i, 19] < 0.08
+    assert len(term) < B // 2
+    for cidx in copies:
+        assert np.array_equal(Sn[cidx], Sn[7]) and f[cidx] == f[7]
+    n = 16
+    small = LocomotionMPC(print_info=False, device=dev, batch=n, n_nodes=30, force_reference="gravity_share")
+    small.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+    Ss = small.open_loop_device(q0[:n], v0[:n], T, push=dict(push, force=force[:n]), record_sim_steps=False)
+    assert np.array_equal(Ss.cpu().numpy(), Sn[:n]) and np.array_equal(small.failed.cpu().numpy(), f[:n])
