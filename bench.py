@@ -325,7 +325,39 @@ def wholebody_legs(a, dev, want_cpu):
         out[key] = leg
         del su
     out["wholebody"]["single_problem_latency"] = single_solve_latency(dev)
+    out["wholebody"]["device_rollouts"] = wholebody_rollouts(B, dev)
     return out
+
+
+def wholebody_rollouts(B, dev):
+    """B pushed whole-body rollouts of 2 s (the reference's own problem through `LocomotionMPC.open_loop_device`: 50 replans, the
+    first one 15 SQP iterations, prepare -> solve -> advance on the device, no host round trip inside a rollout)."""
+    import warnings
+    from iterative_learning_nmpc_amd import wholebody as wbk
+    from iterative_learning_nmpc_amd.mpc_wholebody import LocomotionMPC
+    rng = np.random.default_rng(0)
+    q0 = np.zeros((B, 18)); q0[:, 2] = 0.30; q0[:, 6:] = wbk.Q_HOME + rng.normal(0, 0.03, (B, 12))
+    v0 = np.zeros((B, 18))
+    force = rng.uniform(-1, 1, (B, 3)); force /= np.linalg.norm(force, axis=1, keepdims=True); force *= rng.uniform(50, 70, (B, 1))
+    force[0] = 0.0
+    push = dict(start=0.2, duration=0.3, force=force)
+    times = []
+    for it in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mpc = LocomotionMPC(print_info=False, device=dev, batch=B, n_nodes=30, force_reference="gravity_share")
+        mpc.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
+        mpc.solver._device_solver()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S = mpc.open_loop_device(q0, v0, 2.0, push=push, record_sim_steps=False)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        flags = mpc.failed
+        del mpc
+    el = times[-1]
+    return {"rollouts": B, "replans": int(S.shape[1]), "seconds": el, "rollouts_per_s": B / el, "solver_failures": int((flags & 1).ne(0).sum().item()),
+            "terminated_early": int((flags >> 8).ne(0).sum().item()), "finite": bool(torch.isfinite(S).all().item())}
 
 
 def single_solve_latency(dev):

@@ -65,6 +65,8 @@ def test_default_line_carries_every_gpu_configuration():
         assert ROOFLINE_KEYS <= set(leg["roofline"]) and 0 < leg["roofline"]["frac"] < 1
         assert leg["parity"]["rel_l2_X"] < 1e-5 and leg["parity"]["rel_l2_U"] < 1e-5, (key, leg["parity"])
     assert d["wholebody"]["cpu_baseline"]["kind"] == "port" and d["wholebody"]["cpu_baseline"]["value"] > 0
+    wr = d["wholebody"]["device_rollouts"]
+    assert wr["rollouts"] == 64 and wr["replans"] in (50, 51) and wr["rollouts_per_s"] > 0 and wr["solver_failures"] == 0 and wr["finite"]
     assert "bf16" in d["mixed_precision"]["dtype"]
     r = d["rollouts"]
     assert r["workload"].startswith("configs[3]") and r["rollouts_per_s"] > 0 and r["failed_rollouts"] == 0
