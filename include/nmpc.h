@@ -40,13 +40,16 @@ extern "C" {
  * kernel (by default chosen per call from batch size and horizon; results are bit-identical). */
 #define NMPC_MODEL_DOUBLE_INTEGRATOR 0 /* nx 4  nu 2  np 0  ng 4  (BASELINE config 1) */
 #define NMPC_MODEL_CENTROIDAL        1 /* nx 12 nu 12 np 16 ng 16 (BASELINE config 2) */
-#define NMPC_MODEL_WHOLEBODY         2 /* nx 42 nu 30 np 20 ng 16, ny 82, ny_e 58 (BASELINE configs[2]):
+#define NMPC_MODEL_WHOLEBODY         2 /* nx 42 nu 30 np 20 ng 16, ny 90, ny_e 66 (BASELINE configs[2]):
                                         * the problem the reference solves, x = [q18, v18, h6], u = [a18, f12]
                                         * (solver.py:88-92,405-418); per-node params [active(4), peak(4),
                                         * plane_point(4x3)] (solver.py:212-252); cost residuals in the order
                                         * base(12) joint(24) acc(12) swing(4) f_reg(12) contact(12) consist(6),
                                         * terminal base joint swing contact consist (dynamics.py:121-134,
-                                        * solver.py:108-141); model declared in DESIGN.md 3.2.  N <= 64, fp32. */
+                                        * solver.py:108-141), then the foot-placement rows pos(8) on both;
+                                        * model declared in DESIGN.md 3.2.  N <= 64, fp32.  Device arrays of this
+                                        * model must be 8 B aligned, params 16 B (any allocator's are; a view that
+                                        * starts at a problem boundary keeps it) -- checked, NMPC_E_ARG otherwise. */
 
 /* model parameter vector, nmpc_set_model_params(): */
 #define NMPC_MP_DT    0 /* node spacing T/N                                  */

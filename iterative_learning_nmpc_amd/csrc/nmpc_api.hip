@@ -100,6 +100,10 @@ nmpc::wb::WbArgs wb_args(const Handle* h) {
 
 int launch_wb(Handle* h, nmpc::wb::WbArgs a, hipStream_t st) {
     if (h->line_search) return fail(h, NMPC_E_ARG, "the whole-body model takes full steps (line_search = 0)");
+    // the linearisation reads rows of 42, 30, 90 / 66 floats in 8 B pieces and parameter rows in 16 B pieces (include/nmpc.h)
+    auto misaligned = [](const void* p, unsigned m) { return (reinterpret_cast<uintptr_t>(p) & (m - 1u)) != 0; };
+    if (misaligned(a.x0, 8) || misaligned(a.yref, 8) || misaligned(a.yref_e, 8) || misaligned(a.X, 8) || misaligned(a.U, 8) || misaligned(a.params, 16))
+        return fail(h, NMPC_E_ARG, "whole-body arrays must be 8 B aligned (params: 16 B)");
     const nmpc::wb::WbLds L(a.N);
     const size_t bytes = (size_t)L.total * sizeof(float);
     if (bytes > 64 * 1024)
@@ -266,7 +270,7 @@ int nmpc_create(const nmpc_dims* dims, int device_id, void** handle) {
     if (e == hipSuccess) e = hipMemset(h->ws, 0, h->ws_bytes);
     if (e == hipSuccess) {
         const size_t per = (size_t)dims->N * h->ny + h->nye + (size_t)(dims->N + 1) * (np > 0 ? np : 1) + nx;   // yref, yref_e, params, x0 of the rollouts
-        e = hipMalloc(reinterpret_cast<void**>(&h->roll), (size_t)dims->B_max * per * sizeof(float));
+        e = hipMalloc(reinterpret_cast<void**>(&h->roll), ((size_t)dims->B_max * per + 16) * sizeof(float));   // (+ the 16 B roundings of the carve-up)
     }
     if (e != hipSuccess) {
         g_create_error = std::string("nmpc_create: ") + hipGetErrorString(e);
@@ -578,10 +582,11 @@ int nmpc_wb_rollout_batch(void* handle, int B, const nmpc_wb_rollout_cfg* cfg, c
         HIP_TRY(h, hipMemsetAsync(h->ws, 0, h->ws_bytes, st));
         h->ws_dirty = false;
     }
+    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };       // every array starts on a 16 B boundary (launch_wb checks)
     float* yref = h->roll;
-    float* yref_e = yref + (size_t)h->dims.B_max * N * h->ny;
-    float* params = yref_e + (size_t)h->dims.B_max * h->nye;
-    float* x0 = params + (size_t)h->dims.B_max * (N + 1) * h->np;
+    float* yref_e = yref + up4((size_t)h->dims.B_max * N * h->ny);
+    float* params = yref_e + up4((size_t)h->dims.B_max * h->nye);
+    float* x0 = params + up4((size_t)h->dims.B_max * (N + 1) * h->np);
     nmpc::wb::WbRolloutArgs r{};
     r.B = B; r.N = N; r.npc = cfg->nodes_per_cycle; r.replanning_steps = cfg->replanning_steps; r.n_replans = cfg->n_replans;
     r.record_sim_steps = cfg->record_sim_steps ? 1 : 0; r.force_gravity = cfg->force_reference_gravity ? 1 : 0;

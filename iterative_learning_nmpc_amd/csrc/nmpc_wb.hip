@@ -137,28 +137,41 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
     const float dt = mp.dt;
     const float* Xg = a.X + (size_t)b * (N + 1) * NX;
     const float* Ug = a.U + (size_t)b * N * NU;
-    float* rec = ws + wl.rec + (size_t)k * REC;
+    // alignments the vectoriser may rely on (a lane is a node: every access of this kernel is strided across the wave, so its
+    // cost is the number of memory instructions -- 16 B pieces of the record instead of 210 dword stores, 8 B pieces of x, u, yref).
+    // Workspace: 256 B; caller's arrays: 8 B (x, u, references: rows of 42, 30, 90 / 66 floats) and 16 B (parameters), checked by
+    // the C-ABI (nmpc_api.hip, launch_wb).
+    float* rec = static_cast<float*>(__builtin_assume_aligned(ws + wl.rec + (size_t)k * REC, 16));
     float* js = ws + wl.js + (size_t)k * JS_FLOATS;
 
     float x[NX], u[NU], p[NP];
-    const float* xk = Xg + (size_t)shifted_node(k, a.shift, N) * NX;
+    const float* xk = static_cast<const float*>(__builtin_assume_aligned(Xg + (size_t)shifted_node(k, a.shift, N) * NX, 8));
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = xk[i];
+    for (int i = 0; i < NX; i += 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(xk + i); x[i] = v[0]; x[i + 1] = v[1]; }
     const int ks = term ? 0 : k;
     {
         // warm-start shift as an index map; in the exposed tail the contact forces are zero and the accelerations keep the
         // previous solution's values at that stage (solver.py:316-322 moves a[:, :n_warm_start] and zeroes f[:, n_warm_start:])
         const bool ok = (a.shift == 0) || shifted_stage_valid(ks, a.shift, N);
-        const float* uk = Ug + (size_t)(ok ? ks + a.shift : ks) * NU;
+        const float* uk = static_cast<const float*>(__builtin_assume_aligned(Ug + (size_t)(ok ? ks + a.shift : ks) * NU, 8));
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = (ok || i < WF) ? uk[i] : 0.0f;
+        for (int i = 0; i < NU; i += 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(uk + i);
+            u[i] = (ok || i < WF) ? v[0] : 0.0f; u[i + 1] = (ok || i + 1 < WF) ? v[1] : 0.0f;
+        }
     }
-    const float* pg = a.params + ((size_t)b * (N + 1) + k) * NP;
+    const float* pg = static_cast<const float*>(__builtin_assume_aligned(a.params + ((size_t)b * (N + 1) + k) * NP, 16));
+    static_assert(NX % 2 == 0 && NU % 2 == 0 && NY % 2 == 0 && NYE % 2 == 0 && NP % 4 == 0 && REC % 4 == 0, "row alignments");
 #pragma unroll
-    for (int i = 0; i < NP; ++i) p[i] = pg[i];
+    for (int i = 0; i < NP; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pg + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[i + r] = v[r];
+    }
     const int ny = term ? NYE : NY;
-    const float* yr = term ? a.yref_e + (size_t)b * NYE
-                           : a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) + (a.yref_per_stage ? (size_t)k * NY : 0);
+    const float* yr = static_cast<const float*>(__builtin_assume_aligned(
+        term ? a.yref_e + (size_t)b * NYE
+             : a.yref + (size_t)b * (a.yref_per_stage ? (size_t)N * NY : (size_t)NY) + (a.yref_per_stage ? (size_t)k * NY : 0), 8));
     const float* Wv = term ? a.We : a.W;
     const int r_sw = term ? RE_SWING : RY_SWING, r_ct = term ? RE_CNT : RY_CNT, r_cs = term ? RE_CONS : RY_CONS;
     const int r_ps = term ? RE_POS : RY_POS;
@@ -173,8 +186,22 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
     float cost = 0.0f;
     // element (row, col) of the scaled residual Jacobian image; col 42 = scaled residual value
     auto put_js = [&](int row, int col, float v) { js[((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)] = v; };
+    auto put_js3 = [&](int row, int col, float v0, float v1, float v2) {       // rows row .. row + 2 of one tile
+        typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+        *reinterpret_cast<f32x3u*>(js + ((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)) = f32x3u{v0, v1, v2};
+    };
 
+    // a run of the record, from registers, in 16 B pieces (`off` a multiple of four)
+    auto put_rec = [&](int off, const auto& v) {
+        constexpr int n = (int)(sizeof(v) / sizeof(float));
+        static_assert(n % 4 == 0, "record runs are whole 16 B pieces");
+#pragma unroll
+        for (int i = 0; i < n; i += 4) *reinterpret_cast<f32x4*>(rec + off + i) = f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]};
+    };
     float tau_acc[3] = {0.f, 0.f, 0.f}, F[3] = {0.f, 0.f, 0.f};
+    float hfr[36], cdt[4] = {0.f, 0.f, 0.f, 0.f};      // d h_ang+ / d f [3][12] and dt c_f of the record
+#pragma unroll
+    for (int i = 0; i < 36; ++i) hfr[i] = 0.0f;
     float hq[3][15];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -241,21 +268,26 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
             for (int c = 0; c < 9; ++c) put_js(12 + f, WQ + xi_col(f, c), sw * peak * J[2][c]);
             put_js(12 + f, HX, sw * res);
         }
-        // contact rows: c (J v + p_gain e_z (z - plane_z)) - ref
+        // contact rows: c (J v + p_gain e_z (z - plane_z)) - ref.  The three rows of a foot are neighbours in a column of the
+        // image: one 12 B store per column instead of three dwords
+        {
+            float sres[3], swc[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float vel = 0.0f;
+            for (int i = 0; i < 3; ++i) {
+                float vel = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) vel += J[i][c] * x[WV + xi_col(f, c)];
-            const float w = Wv[r_ct + 3 * f + i], sw = sqrtf(w);
-            const float res = cf * (vel + (i == 2 ? mp.p_gain * (pz - ppz) : 0.0f)) - yr[r_ct + 3 * f + i];
-            cost += 0.5f * w * res * res;
+                for (int c = 0; c < 9; ++c) vel += J[i][c] * x[WV + xi_col(f, c)];
+                const float w = Wv[r_ct + 3 * f + i], sw = sqrtf(w);
+                const float res = cf * (vel + (i == 2 ? mp.p_gain * (pz - ppz) : 0.0f)) - yr[r_ct + 3 * f + i];
+                cost += 0.5f * w * res * res;
+                sres[i] = sw * res; swc[i] = sw * cf;
+            }
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                put_js(3 * f + i, WQ + xi_col(f, c), sw * cf * (Jd[i][c] + (i == 2 ? mp.p_gain * J[2][c] : 0.0f)));
-                put_js(3 * f + i, WV + xi_col(f, c), sw * cf * J[i][c]);
+                put_js3(3 * f, WQ + xi_col(f, c), swc[0] * Jd[0][c], swc[1] * Jd[1][c], swc[2] * (Jd[2][c] + mp.p_gain * J[2][c]));
+                put_js3(3 * f, WV + xi_col(f, c), swc[0] * J[0][c], swc[1] * J[1][c], swc[2] * J[2][c]);
             }
-            put_js(3 * f + i, HX, sw * res);
+            put_js3(3 * f, HX, sres[0], sres[1], sres[2]);
         }
         if (!term) {   // momentum rows of the dynamics
             const float ff[3] = {u[WF + 3 * f], u[WF + 3 * f + 1], u[WF + 3 * f + 2]};
@@ -276,8 +308,8 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) rec[R_HF + i * 12 + 3 * f + j] = dt * cf * ax[3 * i + j];
-            rec[R_CDT + f] = dt * cf;
+                for (int j = 0; j < 3; ++j) hfr[i * 12 + 3 * f + j] = dt * cf * ax[3 * i + j];
+            cdt[f] = dt * cf;
         }
     }
     // ---- consistency rows  h - A_g(q) v,  A_g v = [m rdot ; R I_b E(theta) thetadot]
@@ -332,15 +364,21 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         }
     }
     // ---- diagonal residuals (base, joint) on x[0..35]: gradient and cost
+    {
+        float gq[36];
 #pragma unroll
-    for (int s = 0; s < 36; ++s) {
-        const float w = wdiag(a, s, term);
-        const float e = x[s] - yr[yref_of_state(s)];
-        rec[R_GQ + s] = w * e;
-        cost += 0.5f * w * e * e;
+        for (int s = 0; s < 36; ++s) {
+            const float w = wdiag(a, s, term);
+            const float e = x[s] - yr[yref_of_state(s)];
+            gq[s] = w * e;
+            cost += 0.5f * w * e * e;
+        }
+        put_rec(R_GQ, gq);
     }
     if (!term) {
         // input residuals: acc on a[6..17], f_reg on f
+        float rr[32];
+        rr[30] = rr[31] = 0.0f;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             float g = 0.0f;
@@ -351,37 +389,50 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                 const float w = a.W[RY_FREG + i - WF], e = u[i] - yr[RY_FREG + i - WF];
                 g = w * e; cost += 0.5f * w * e * e;
             }
-            rec[R_R + i] = g;
+            rr[i] = g;
         }
+        put_rec(R_R, rr);
         // dynamics defect
-        const float* xn_g = Xg + (size_t)shifted_node(k + 1, a.shift, N) * NX;
+        const float* xn_g = static_cast<const float*>(__builtin_assume_aligned(Xg + (size_t)shifted_node(k + 1, a.shift, N) * NX, 8));
+        float xn[NX], dd[44];
+#pragma unroll
+        for (int i = 0; i < NX; i += 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(xn_g + i); xn[i] = v[0]; xn[i + 1] = v[1]; }
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const float vn = x[WV + i] + dt * u[WA + i];
-            rec[R_D + WV + i] = vn - xn_g[WV + i];
-            rec[R_D + WQ + i] = x[WQ + i] + dt * vn - xn_g[WQ + i];
+            dd[WV + i] = vn - xn[WV + i];
+            dd[WQ + i] = x[WQ + i] + dt * vn - xn[WQ + i];
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            rec[R_D + WH + i] = x[WH + i] + dt * (F[i] + (i == 2 ? mp.mass * mp.gz : 0.0f)) - xn_g[WH + i];
-            rec[R_D + WH + 3 + i] = x[WH + 3 + i] + dt * tau_acc[i] - xn_g[WH + 3 + i];
+            dd[WH + i] = x[WH + i] + dt * (F[i] + (i == 2 ? mp.mass * mp.gz : 0.0f)) - xn[WH + i];
+            dd[WH + 3 + i] = x[WH + 3 + i] + dt * tau_acc[i] - xn[WH + 3 + i];
         }
-        rec[R_D + 42] = 0.0f; rec[R_D + 43] = 0.0f;
-        rec[R_ZERO] = 0.0f; rec[R_DT] = dt; rec[R_DT2] = dt * dt;
+        dd[42] = 0.0f; dd[43] = 0.0f;
+        put_rec(R_D, dd);
+        {
+            float hq16[48];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 15; ++j) rec[R_HQ + i * 16 + j] = hq[i][j];
+                for (int j = 0; j < 16; ++j) hq16[i * 16 + j] = j < 15 ? hq[i][j < 15 ? j : 0] : 0.0f;
+            put_rec(R_HQ, hq16);
+        }
+        put_rec(R_HF, hfr);
+        put_rec(R_CDT, cdt);
         // friction pyramid
         float fv[12], g[NG];
 #pragma unroll
         for (int i = 0; i < 12; ++i) fv[i] = u[WF + i];
         gdot(mp, fv, g);
-#pragma unroll
-        for (int j = 0; j < NG; ++j) rec[R_C + j] = g[j];       // h = 0
-        reinterpret_cast<unsigned*>(rec)[R_ACT] = (a.n_ipm > 0) ? active_mask(p) : 0u;
+        put_rec(R_C, g);       // h = 0
+        static_assert(R_ACT == 180 && R_COST == 181 && R_ZERO == 182 && R_DT == 183 && R_DT2 == 220, "tail of the record");
+        const unsigned act = (a.n_ipm > 0) ? active_mask(p) : 0u;
+        *reinterpret_cast<f32x4*>(rec + R_ACT) = f32x4{__uint_as_float(act), cost, 0.0f, dt};
+        rec[R_DT2] = dt * dt;
+    } else {
+        rec[R_COST] = cost;
     }
-    rec[R_COST] = cost;
 }
 
 // ------------------------------------------------------------------------------------------------------------

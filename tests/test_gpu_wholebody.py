@@ -485,3 +485,29 @@ def test_wholebody_device_rollouts_full_size(dev):
     small.set_command(np.array([0.2, 0.0, 0.0]), 0.0)
     Ss = small.open_loop_device(q0[:n], v0[:n], T, push=dict(push, force=force[:n]), record_sim_steps=False)
     assert np.array_equal(Ss.cpu().numpy(), Sn[:n]) and np.array_equal(small.failed.cpu().numpy(), f[:n])
+
+
+def test_wholebody_refuses_misaligned_arrays(dev):
+    """include/nmpc.h: arrays of the whole-body model are read in 8 B (parameters: 16 B) pieces -- a pointer off those boundaries is
+    an argument error, not a fault; a view that starts at a problem boundary is fine."""
+    from iterative_learning_nmpc_amd import workloads as wl
+    from iterative_learning_nmpc_amd._lib import NmpcError
+    from iterative_learning_nmpc_amd.solver import BatchedNmpcSolver
+    w = wl.wholebody_trot(B=4, N=30, seed=9)
+    s = BatchedNmpcSolver(w.model_id, w.N, w.B, dev)
+    s.set_model_params(w.mp); s.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+    t = {k: s.to_device(getattr(w, k)) for k in ("x0", "yref", "yref_e", "params", "X", "U")}
+    X, U, st, _ = s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], t["X"].clone(), t["U"].clone())
+    assert (st.cpu().numpy() != 1).all()
+    # the last three problems as views into the same storage: aligned, and the same result as in the full batch
+    s3 = BatchedNmpcSolver(w.model_id, w.N, 3, dev)
+    s3.set_model_params(w.mp); s3.set_cost_weights(w.W, w.W_e, w.meta["reg"], w.meta["reg_e"])
+    X3, U3, st3, _ = s3.solve(*(t[k][1:] for k in ("x0", "yref", "yref_e", "params")), t["X"][1:].clone(), t["U"][1:].clone())
+    assert torch.equal(X3, X[1:]) and torch.equal(U3, U[1:])
+    # one float off
+    flat = torch.zeros(t["X"].numel() + 1, dtype=torch.float32, device=dev)
+    Xoff = flat[1:].view_as(t["X"])
+    Xoff.copy_(t["X"])
+    assert Xoff.data_ptr() % 8 == 4
+    with pytest.raises(NmpcError, match="aligned"):
+        s.solve(t["x0"], t["yref"], t["yref_e"], t["params"], Xoff, t["U"].clone())
