@@ -68,6 +68,12 @@ __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y, f32x4 C) {
     return C;
 }
 __device__ __forceinline__ f32x4 xty(f32x4 X, f32x4 Y) { return xty(X, Y, zero4()); }
+// the same over contraction steps 0 and 1 only (registers 2, 3 of one operand are exact zeros in every lane)
+__device__ __forceinline__ f32x4 xty01(f32x4 X, f32x4 Y, f32x4 C) {
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[0], Y[0], C, 0, 0, 0);
+    C = __builtin_amdgcn_mfma_f32_16x16x4f32(X[1], Y[1], C, 0, 0, 0);
+    return C;
+}
 
 // Same product with the K steps split over two accumulators: half the dependent-MFMA depth (a
 // dependent fp32 MFMA costs 44 cycles against 32 issue) for a product that stands alone on the

@@ -32,23 +32,37 @@
 namespace nmpc {
 namespace wb {
 
-constexpr int HX = 42;                 // homogeneous coordinate of x~ = [dx; 1]
+// Positions of the states in the 48-wide homogeneous vector x~ (three tiles of 16).  States 0..35 (q, v_0..v_17) sit at their own
+// index: tiles 0, 1 and slots 0..3 of tile 2.  The six momentum states sit at slots 4, 5, 8, 9, 12, 13 of tile 2 and the
+// homogeneous coordinate at slot 6: registers 0 and 1 of lane rows 1..3 in the accumulator layout.  A product that contracts over
+// tile row 2 against an operand whose only non-zero rows are momentum rows (the dense part of N~ = A~ - I and of B~) then needs
+// contraction steps 0 and 1 only: 34 of 196 MFMAs of a backward stage less than with the states in their own order.
+constexpr int HX = 38;                 // position of the homogeneous coordinate of x~ = [dx; 1]
+constexpr int XW = 46;                 // positions in use: 0..45
+__host__ __device__ constexpr int pos_of(int s) { return s < 36 ? s : 32 + 4 * (1 + (s - 36) / 2) + ((s - 36) & 1); }      // s < 42
+__host__ __device__ constexpr int state_at(int p) {      // -1: padding or the homogeneous coordinate
+    return p < 36 ? p : (p < XW && (p & 3) < 2) ? 36 + 2 * ((p - 36) >> 2) + (p & 1) : -1;
+}
+static_assert(pos_of(36) == 36 && pos_of(37) == 37 && pos_of(38) == 40 && pos_of(39) == 41 && pos_of(40) == 44 && pos_of(41) == 45, "momentum slots");
+static_assert(state_at(40) == 38 && state_at(45) == 41 && state_at(HX) == -1 && state_at(39) == -1 && state_at(46) == -1, "momentum slots");
+constexpr int HXQ = (HX - 32) >> 2, HXR = (HX - 32) & 3;      // lane row and register of row HX in tile row 2
+static_assert(HXR == 2, "the homogeneous row is register 2 of its lane row");
 constexpr int XT = 3, UT = 2;          // 16-wide tiles of the state (48) and input (32) dimensions
 constexpr int JT = 2;                  // K tiles of the dense residual Jacobian (22 rows)
 constexpr int IMG = TILE;              // floats of one tile image (column-major 16x16)
 constexpr int JS_FLOATS = JT * XT * IMG, QT_FLOATS = XT * XT * IMG, KT_FLOATS = UT * XT * IMG;
 
 // per-node record written by the linearisation (float offsets)
-constexpr int R_D = 0;                 // defect d[42] (+2 zeros)
-constexpr int R_HQ = 44;               // d h_ang+ / d q[3..17]: [3][16]
-constexpr int R_HF = 92;               // d h_ang+ / d f: [3][12]
-constexpr int R_CDT = 128;             // dt c_i: d h_lin+ / d f_i = cdt_i I
-constexpr int R_R = 132;               // input gradient r[30] (+2)
-constexpr int R_C = 164;               // friction pyramid values c = G u - h [16]
-constexpr int R_ACT = 180, R_COST = 181;
-constexpr int R_ZERO = 182, R_DT = 183, R_DT2 = 220;   // constants the tile synthesis reads like any other entry
-constexpr int R_GQ = 184;              // gradient of the diagonal residuals on x[0..35]
-constexpr int REC = 224;
+constexpr int R_D = 0;                 // defect d, by POSITION: [48], zero where no state sits
+constexpr int R_HQ = 48;               // d h_ang+ / d q[3..17]: [3][16]
+constexpr int R_HF = 96;               // d h_ang+ / d f: [3][12]
+constexpr int R_CDT = 132;             // dt c_i: d h_lin+ / d f_i = cdt_i I
+constexpr int R_R = 136;               // input gradient r[30] (+2)
+constexpr int R_C = 168;               // friction pyramid values c = G u - h [16]
+constexpr int R_ACT = 184, R_COST = 185;
+constexpr int R_ZERO = 186, R_DT = 187, R_DT2 = 224;   // constants the tile synthesis reads like any other entry
+constexpr int R_GQ = 188;              // gradient of the diagonal residuals on x[0..35]
+constexpr int REC = 228;
 
 struct WbArgs {
     ModelParams mp;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         base_rotation<true>(th, thd, br);
     }
     float cost = 0.0f;
-    // element (row, col) of the scaled residual Jacobian image; col 42 = scaled residual value
+    // element (row, col) of the scaled residual Jacobian image; col = POSITION of the state (pos_of), HX = scaled residual value
     auto put_js = [&](int row, int col, float v) { js[((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)] = v; };
     auto put_js3 = [&](int row, int col, float v0, float v1, float v2) {       // rows row .. row + 2 of one tile
         typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                 const float w = Wv[r_cs + i], sw = sqrtf(w);
                 const float res = x[WH + i] - mp.mass * x[WV + i] - yr[r_cs + i];
                 cost += 0.5f * w * res * res;
-                put_js(16 + i, WH + i, sw);
+                put_js(16 + i, pos_of(WH + i), sw);
                 put_js(16 + i, WV + i, -sw * mp.mass);
                 put_js(16 + i, HX, sw * res);
             }
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                 const float w = Wv[r_cs + 3 + i], sw = sqrtf(w);
                 const float res = x[WH + 3 + i] - L[i] - yr[r_cs + 3 + i];
                 cost += 0.5f * w * res * res;
-                put_js(19 + i, WH + 3 + i, sw);
+                put_js(19 + i, pos_of(WH + 3 + i), sw);
                 put_js(19 + i, HX, sw * res);
             }
         }
@@ -394,7 +408,9 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         put_rec(R_R, rr);
         // dynamics defect
         const float* xn_g = static_cast<const float*>(__builtin_assume_aligned(Xg + (size_t)shifted_node(k + 1, a.shift, N) * NX, 8));
-        float xn[NX], dd[44];
+        float xn[NX], dd[48];
+#pragma unroll
+        for (int i = 36; i < 48; ++i) dd[i] = 0.0f;
 #pragma unroll
         for (int i = 0; i < NX; i += 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(xn_g + i); xn[i] = v[0]; xn[i + 1] = v[1]; }
 #pragma unroll
@@ -405,10 +421,9 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            dd[WH + i] = x[WH + i] + dt * (F[i] + (i == 2 ? mp.mass * mp.gz : 0.0f)) - xn[WH + i];
-            dd[WH + 3 + i] = x[WH + 3 + i] + dt * tau_acc[i] - xn[WH + 3 + i];
+            dd[pos_of(WH + i)] = x[WH + i] + dt * (F[i] + (i == 2 ? mp.mass * mp.gz : 0.0f)) - xn[WH + i];
+            dd[pos_of(WH + 3 + i)] = x[WH + 3 + i] + dt * tau_acc[i] - xn[WH + 3 + i];
         }
-        dd[42] = 0.0f; dd[43] = 0.0f;
         put_rec(R_D, dd);
         {
             float hq16[48];
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         for (int i = 0; i < 12; ++i) fv[i] = u[WF + i];
         gdot(mp, fv, g);
         put_rec(R_C, g);       // h = 0
-        static_assert(R_ACT == 180 && R_COST == 181 && R_ZERO == 182 && R_DT == 183 && R_DT2 == 220, "tail of the record");
+        static_assert(R_ACT % 4 == 0 && R_COST == R_ACT + 1 && R_ZERO == R_ACT + 2 && R_DT == R_ACT + 3 && R_DT2 % 4 == 0, "tail of the record");
         const unsigned act = (a.n_ipm > 0) ? active_mask(p) : 0u;
         *reinterpret_cast<f32x4*>(rec + R_ACT) = f32x4{__uint_as_float(act), cost, 0.0f, dt};
         rec[R_DT2] = dt * dt;
@@ -759,7 +774,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
     for (int i = 0; i < XT; ++i) {
         const int row = 16 * i + c;
-        const bool mine = (c >> 2) == q4 && row < NX;
+        const bool mine = (c >> 2) == q4 && state_at(row) >= 0;
         qdiag[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, false) : 0.0f) + a.reg : 0.0f;
         qdiag_e[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, true) : 0.0f) + a.reg_e : 0.0f;
     }
@@ -973,8 +988,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 const int row = 16 * nt_i[t] + 4 * q4 + r, col = 16 * nt_j[t] + c;
                 int idx = R_ZERO;
                 if (row < 18 && col == row + 18) idx = R_DT;
-                if (col == HX && row < NX) idx = R_D + row;
-                if (row >= 39 && row < 42 && col >= 3 && col < 18) idx = R_HQ + (row - 39) * 16 + (col - 3);
+                const int sr = state_at(row);
+                if (col == HX && sr >= 0) idx = R_D + row;
+                if (sr >= 39 && sr < 42 && col >= 3 && col < 18) idx = R_HQ + (sr - 39) * 16 + (col - 3);
                 nIdx[t][r] = idx;
             }
 #pragma unroll
@@ -984,11 +1000,13 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 const int row = 16 * bt_i[t] + 4 * q4 + r, uc = 16 * bt_j[t] + c;
                 int idx = R_ZERO;
                 if (uc < 18 && row == uc) idx = R_DT2;
-                if (uc < 18 && row == uc + 18) idx = R_DT;
+                // (dt at (v_16, a_16), (v_17, a_17) of tile (2,1) is applied without the matrix pipe, so that the tile's only non-zero
+                //  rows are momentum rows: contraction steps 0, 1)
+                if (uc < 18 && row == uc + 18 && !(bt_i[t] == 2 && bt_j[t] == 1)) idx = R_DT;
                 if (uc >= WF && uc < NU) {
-                    const int f = uc - WF;
-                    if (row >= 36 && row < 39 && row - 36 == f % 3) idx = R_CDT + f / 3;
-                    if (row >= 39 && row < 42) idx = R_HF + (row - 39) * 12 + f;
+                    const int f = uc - WF, sr = state_at(row);
+                    if (sr >= 36 && sr < 39 && sr - 36 == f % 3) idx = R_CDT + f / 3;
+                    if (sr >= 39 && sr < 42) idx = R_HF + (sr - 39) * 12 + f;
                 }
                 bIdx[t][r] = idx;
             }
@@ -1024,16 +1042,16 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) rs_free[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
     const float dt2 = dt * dt;
-    const float dt2_c01 = (c < 2) ? dt2 : 0.0f;
+    const float dt2_c01 = (c < 2) ? dt2 : 0.0f, dt_c01 = (c < 2) ? dt : 0.0f;
     const int up_addr = 4 * ((lane + 16) & 63);
     const bool last_row = lane >= 48;
     const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
     const float dt_q0 = (q4 == 0) ? dt : 0.0f;
-    const bool hx_col = (c == HX - 32), hx_row = (q4 == 2);       // HX = 42: column 10 of tile column 2; row 10 of tile row 2 = quad 2, register 2
+    const bool hx_col = (c == HX - 32), hx_row = (q4 == HXQ);     // HX = 38: column 6 of tile column 2; row 6 of tile row 2 = lane row 1, register 2
     // where this lane finds, in the stage record, the defects of its columns (one per tile column) ...
     int dcolIdx[XT];
 #pragma unroll
-    for (int kk = 0; kk < XT; ++kk) dcolIdx[kk] = (16 * kk + c < NX) ? R_D + 16 * kk + c : R_ZERO;
+    for (int kk = 0; kk < XT; ++kk) dcolIdx[kk] = R_D + 16 * kk + c;      // (the record holds zeros where no state sits)
     float dt2_r01[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
@@ -1112,9 +1130,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int kk = 0; kk < XT; ++kk) {
                 dcol[kk] = rk[dcolIdx[kk]];
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(rk + R_D + ((16 * kk + 4 * q4 < 44) ? 16 * kk + 4 * q4 : 40));
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(rk + R_D + 16 * kk + 4 * q4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) drow[kk][r] = (16 * kk + 4 * q4 < 44) ? d4[r] : 0.0f;
+                for (int r = 0; r < 4; ++r) drow[kk][r] = d4[r];
             }
             WB_STAMP(1);
             // ---- P~A~ = P~ + P~N~ ,  P~B~
@@ -1151,7 +1169,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     }
 #pragma unroll
                     for (int kk = 0; kk < XT; ++kk)
-                        if (n_tile_nonzero(kk, j) && !(kk == 0 && j == 1) && j != 2) acc = xty(P[kk][i], Nt[kk][j], acc);
+                        if (n_tile_nonzero(kk, j) && !(kk == 0 && j == 1) && j != 2) {
+                            static_assert(XT == 3, "the dense tiles of N~ are those of tile row 2");
+                            if (kk == 2) acc = xty01(P[kk][i], Nt[kk][j], acc);      // momentum rows only: steps 0, 1
+                        }
                     PA[i][j] = acc;
                 }
                 {   // j = 0 (inputs a_0..a_15): (P~ B~)[:, a_c] = dt^2 P~[:, c] + dt P~[:, 18 + c]
@@ -1169,8 +1190,11 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     // place, scaled; the rest (dt at v_16, v_17 and the wrench map of the forces) is the tile B~(2,1)
                     f32x4 acc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = dt2_c01 * P[i][1][r];
-                    PB[i][1] = xty(P[2][i], Bt[2][1], acc);
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] = dt2_c01 * P[i][1][r];
+                        acc[r] = __builtin_fmaf(dt_c01, dpp_row<0x102>(P[i][2][r]), acc[r]);      // dt at (v_16, a_16), (v_17, a_17): columns 34, 35 onto lanes 0, 1
+                    }
+                    PB[i][1] = xty01(P[2][i], Bt[2][1], acc);      // the wrench map of the forces: momentum rows only
                 }
             }
             WB_STAMP(2);
@@ -1223,11 +1247,26 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     Huu[0][0][2] = __builtin_fmaf(dt, rows_up(PB[1][0][0], PB[2][0][0], up_addr, last_row), Huu[0][0][2]);
                     Huu[0][0][3] = __builtin_fmaf(dt, rows_up(PB[1][0][1], PB[2][0][1], up_addr, last_row), Huu[0][0][3]);
                 }
+                if (i == 1) {
+                    // kk = 2, inputs a_16, a_17: dt at (v_16, a_16), (v_17, a_17) -- rows 34, 35 of X (registers 2, 3 of lane row 0 of tile
+                    // row 2) onto rows a_16, a_17 (registers 0, 1 of lane row 0)
+#pragma unroll
+                    for (int j = 0; j < XT; ++j) {
+                        Hux[1][j][0] = __builtin_fmaf(dt_q0, PA[2][j][2], Hux[1][j][0]);
+                        Hux[1][j][1] = __builtin_fmaf(dt_q0, PA[2][j][3], Hux[1][j][1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j <= 1; ++j) {
+                        Huu[1][j][0] = __builtin_fmaf(dt_q0, PB[2][j][2], Huu[1][j][0]);
+                        Huu[1][j][1] = __builtin_fmaf(dt_q0, PB[2][j][3], Huu[1][j][1]);
+                    }
+                }
 #pragma unroll
                 for (int kk = 0; kk < XT; ++kk)
                     if (b_tile_nonzero(kk, i) && kk != i && i != 0) {
+                        static_assert(XT == 3, "the one dense tile of B~ left for the matrix pipe is (2,1): momentum rows, steps 0, 1");
 #pragma unroll
-                        for (int st = 0; st < 4; ++st) {
+                        for (int st = 0; st < 2; ++st) {
 #pragma unroll
                             for (int j = 0; j < XT; ++j) Hux[i][j] = mfma4(Bt[kk][i][st], PA[kk][j][st], Hux[i][j]);
 #pragma unroll
@@ -1279,7 +1318,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     for (int kk = 0; kk < XT; ++kk)
                         if (n_tile_nonzero(kk, i)) {
 #pragma unroll
-                            for (int st = 0; st < 4; ++st)
+                            for (int st = 0; st < (kk == 2 ? 2 : 4); ++st)      // tile row 2 of N~: momentum rows only
 #pragma unroll
                                 for (int j = 0; j <= i; ++j) H[i][j] = mfma4(Nt[kk][i][st], PA[kk][j][st], H[i][j]);
                         }
@@ -1447,10 +1486,12 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // requested FWD_PF stages ahead in a register ring, the stage record two stages ahead (registers -> LDS).
         float* oX = use_ipm ? dXp : dX;
         float* oU = use_ipm ? dUp : dU;
-        float xcur = 0.0f;                                  // lane i < 42: dx_i; lane 42: the homogeneous 1
-        if (lane < NX) xcur = x0[lane] - Xg[lane];          // node 0 is not moved by the warm-start shift
+        // lanes are POSITIONS of x~ (pos_of): lane p holds dx of the state that sits there, lane HX the homogeneous 1, the others 0
+        const int sl = state_at(lane);
+        float xcur = 0.0f;
+        if (sl >= 0) xcur = x0[sl >= 0 ? sl : 0] - Xg[sl >= 0 ? sl : 0];          // node 0 is not moved by the warm-start shift
         if (lane == HX) xcur = 1.0f;
-        if (lane < NX) AT(oX, 0, lane) = xcur;
+        if (sl >= 0) AT(oX, 0, sl) = xcur;
         float* const rbuf[2] = {recb, hbuf};                // stage records, double-buffered (hbuf is free in this phase)
         const unsigned rec_lane = (4 * lane < REC) ? 4 * lane : 0;
         auto load_rec = [&](int k) { return *reinterpret_cast<const f32x4*>(recs + (size_t)(k < N ? k : N - 1) * REC + rec_lane); };
@@ -1459,53 +1500,53 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         wave_sync();
         const int urow = lane < NU ? lane : 0;
         // the gain images hold K~' (states x inputs, column-major): row `urow` of K~ is one contiguous column per state tile,
-        // eleven 16 B loads per lane instead of 43 dwords (the CU's address path takes 16 cycles per wave-instruction)
+        // eleven 16 B loads + one of 8 B per lane instead of 43 dwords (the CU's address path takes 16 cycles per wave-instruction)
         const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15) * TS);
-        auto load_krow = [&](int k, float (&row)[HX + 1]) {
+        auto load_krow = [&](int k, float (&row)[XW]) {
             const float* Kk = Kimg + (size_t)(k < N ? k : N - 1) * KT_FLOATS + krow_off;
 #pragma unroll
-            for (int j4 = 0; j4 < 10; ++j4) {
+            for (int j4 = 0; j4 < 11; ++j4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(Kk + (j4 >> 2) * IMG + 4 * (j4 & 3));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) row[4 * j4 + r] = v[r];
             }
-            // elements 40 .. 42 as 8 + 4 bytes: a fourth, unused register of a 16 B load is free for reuse at once, and whatever is
-            // written to it next waits for the load to land (write after write) -- that wait sat in the middle of the NEXT stage,
-            // behind all the row loads issued before it (vmcnt retires in order), and undid the prefetch
-            const f32x2 v2 = *reinterpret_cast<const f32x2*>(Kk + 2 * IMG + 8);
-            row[40] = v2[0]; row[41] = v2[1];
-            row[42] = Kk[2 * IMG + 10];
-            static_assert(HX == 42, "row tail");
+            // positions 44, 45 as 8 bytes, and EVERY loaded element is used below (the padding positions meet dx~ = 0): an unused
+            // register of a 16 B load is free for reuse at once, and whatever is written to it next waits for the load to land
+            // (write after write) -- that wait sat in the middle of the NEXT stage, behind all the row loads issued before it
+            // (vmcnt retires in order), and undid the prefetch
+            const f32x2 v2 = *reinterpret_cast<const f32x2*>(Kk + 2 * IMG + 12);
+            row[44] = v2[0]; row[45] = v2[1];
+            static_assert(XW == 46, "row tail");
         };
-        const int fi = lane < NX ? lane : 0;
+        const int fi = sl >= 0 ? sl : 0;
         const int hr = (fi >= 39) ? fi - 39 : 0, lr = (fi >= 36 && fi < 39) ? fi - 36 : 0;
         const int x_addr = 4 * (lane < 18 ? lane + 18 : (lane < 36 ? lane - 18 : lane));      // q rows take dx of their v row, v rows du of their q row
         constexpr int FWD_PF = 2;
-        float ring[FWD_PF][HX + 1];
+        float ring[FWD_PF][XW];
 #pragma unroll
         for (int pf = 0; pf < FWD_PF; ++pf) load_krow(pf, ring[pf]);
-        auto fwd_stage = [&](int k, float (&row)[HX + 1]) {
+        auto fwd_stage = [&](int k, float (&row)[XW]) {
             const float* rk = rbuf[k & 1];
             const f32x4 rec_next = rec_ahead;                // stage k + 1's record, requested a stage ago
             rec_ahead = load_rec(k + 2);
             // what this lane needs of the stage record (not on the dependent chain: the record has been in the LDS for a stage)
-            const float d_i = rk[R_D + fi];
+            const float d_i = rk[R_D + (lane < 48 ? lane : 0)];      // (the record's defect is stored by position)
             f32x4 hq4[4], hf4[3];
 #pragma unroll
             for (int v4 = 0; v4 < 4; ++v4) hq4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HQ + hr * 16 + 4 * v4);
 #pragma unroll
             for (int v4 = 0; v4 < 3; ++v4) hf4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12 + 4 * v4);
             const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
-            float dxs[HX];
+            float dxs[XW];
 #pragma unroll
-            for (int j = 0; j < HX; ++j) dxs[j] = bcast(xcur, j);
+            for (int j = 0; j < XW; ++j) dxs[j] = bcast(xcur, j);
             float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
-            for (int j4 = 0; j4 < 11; ++j4) {
+            for (int j4 = 0; j4 < 12; ++j4) {
                 a0 = fmaf(row[4 * j4], dxs[4 * j4], a0);
                 a1 = fmaf(row[4 * j4 + 1], dxs[4 * j4 + 1], a1);
-                a2 = fmaf(row[4 * j4 + 2], (4 * j4 + 2 < HX) ? dxs[4 * j4 + 2 < HX ? 4 * j4 + 2 : 0] : 1.0f, a2);      // dx~[HX] = 1
-                if (4 * j4 + 3 <= HX) a3 = fmaf(row[(4 * j4 + 3 <= HX) ? 4 * j4 + 3 : 0], dxs[(4 * j4 + 3 < HX) ? 4 * j4 + 3 : 0], a3);
+                if (4 * j4 + 2 < XW) a2 = fmaf(row[4 * j4 + 2 < XW ? 4 * j4 + 2 : 0], dxs[4 * j4 + 2 < XW ? 4 * j4 + 2 : 0], a2);
+                if (4 * j4 + 3 < XW) a3 = fmaf(row[4 * j4 + 3 < XW ? 4 * j4 + 3 : 0], dxs[4 * j4 + 3 < XW ? 4 * j4 + 3 : 0], a3);
             }
             const float du = (a0 + a1) + (a2 + a3);
             load_krow(k + FWD_PF, row);                      // refill the ring slot after its last use
@@ -1539,8 +1580,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             xn += (fi >= 39) ? acc_a : (fi >= 36) ? acc_l : 0.0f;
             WB_STAMP(14);
-            if (lane < NX) AT(oX, k + 1, lane) = xn;
-            xcur = (lane < NX) ? xn : (lane == HX ? 1.0f : 0.0f);
+            if (sl >= 0) AT(oX, k + 1, sl) = xn;
+            xcur = (sl >= 0) ? xn : (lane == HX ? 1.0f : 0.0f);
             *reinterpret_cast<f32x4*>(rbuf[(k + 1) & 1] + 4 * lane) = rec_next;
             wave_sync();
             WB_STAMP(15);
