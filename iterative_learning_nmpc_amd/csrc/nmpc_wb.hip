@@ -1044,6 +1044,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     const float dt2 = dt * dt;
     const float dt2_c01 = (c < 2) ? dt2 : 0.0f, dt_c01 = (c < 2) ? dt : 0.0f;
     const int up_addr = 4 * ((lane + 16) & 63);
+    const int down_addr = 4 * ((lane + 48) & 63);               // the lane one lane row (16 lanes) before this one
+    const float dt_qn0 = (q4 > 0) ? dt : 0.0f;
     const bool last_row = lane >= 48;
     const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
     const float dt_q0 = (q4 == 0) ? dt : 0.0f;
@@ -1113,10 +1115,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
                 Nt[0][0] = Nt[1][0] = Nt[1][1] = zero4();
                 Bt[0][1] = zero4();
-                Nt[0][2] = Nt[1][2] = Nt[2][2] = zero4();       // (their products are formed without the matrix pipe, see below)
+                Nt[0][1] = Nt[0][2] = Nt[1][2] = Nt[2][2] = zero4();       // (their products are formed without the matrix pipe, see below)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    if (nt_j[t] != 2) {
+                    if (nt_j[t] != 2 && nt_i[t] == 2) {      // the dense tiles: momentum rows against q (2,0), (2,1)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) Nt[nt_i[t]][nt_j[t]][r] = rk[nIdx[t][r]];
                     }
@@ -1314,11 +1316,25 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                         H[2][j][2] += hx_row ? t : 0.0f;
                     }
                 } else {
+                    if (i == 1) {
+                        // N~(0,1)'(P~A~): N~(0,1) holds nothing but dt at (q_c, v_c), c < 14 -- rows v_c = 18 + c of H take dt x row c of P~A~:
+                        // rows 4q, 4q+1 of tile row 0 onto rows 4q+2, 4q+3 of tile row 1 (registers 0, 1 -> 2, 3 of the same lane), rows
+                        // 4q+2, 4q+3 onto rows 4(q+1), 4(q+1)+1 (registers 2, 3 -> 0, 1 one lane row further on: one crossbar move each)
+#pragma unroll
+                        for (int j = 0; j <= 1; ++j) {
+                            const float d2 = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][2])));
+                            const float d3 = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][3])));
+                            H[1][j][0] = __builtin_fmaf(dt_qn0, d2, H[1][j][0]);
+                            H[1][j][1] = __builtin_fmaf(dt_qn0, d3, H[1][j][1]);
+                            H[1][j][2] = __builtin_fmaf(dt, PA[0][j][0], H[1][j][2]);
+                            H[1][j][3] = __builtin_fmaf(dt, PA[0][j][1], H[1][j][3]);
+                        }
+                    }
 #pragma unroll
                     for (int kk = 0; kk < XT; ++kk)
-                        if (n_tile_nonzero(kk, i)) {
+                        if (n_tile_nonzero(kk, i) && kk == 2) {      // tile row 2 of N~: momentum rows only, contraction steps 0, 1
 #pragma unroll
-                            for (int st = 0; st < (kk == 2 ? 2 : 4); ++st)      // tile row 2 of N~: momentum rows only
+                            for (int st = 0; st < 2; ++st)
 #pragma unroll
                                 for (int j = 0; j <= i; ++j) H[i][j] = mfma4(Nt[kk][i][st], PA[kk][j][st], H[i][j]);
                         }
