@@ -970,94 +970,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         ipm_terms(tau, sj, lj, cj, rr);
     };
 
-    // per-lane constants of the tile synthesis: every element of N~ = A~ - I, B~, R~ and S~ is ONE LDS read at a
-    // precomputed index -- into the stage record (defect, momentum Jacobians, or one of its constant slots 0, dt, dt^2)
-    // or into the stage's row of barrier-modified input terms.  (Lane predicates instead of indices cost an SGPR pair
-    // per element and tile: the loop-invariant masks spilled 626 SGPRs into VGPR lanes.)
-    constexpr int NT = 6, BT = 5;
-    // non-zero tiles of N~: (0,1) (0,2) (1,2) (2,0) (2,1) (2,2) ; of B~: (0,0) (1,0) (1,1) (2,0) (2,1)
-    int nIdx[NT][4], bIdx[BT][4], rIdx[4], sIdx[UT][4];
-    float rdiag[UT][4];
-    {
-        constexpr int nt_i[NT] = {0, 0, 1, 2, 2, 2}, nt_j[NT] = {1, 2, 2, 0, 1, 2};
-        constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * nt_i[t] + 4 * q4 + r, col = 16 * nt_j[t] + c;
-                int idx = R_ZERO;
-                if (row < 18 && col == row + 18) idx = R_DT;
-                const int sr = state_at(row);
-                if (col == HX && sr >= 0) idx = R_D + row;
-                if (sr >= 39 && sr < 42 && col >= 3 && col < 18) idx = R_HQ + (sr - 39) * 16 + (col - 3);
-                nIdx[t][r] = idx;
-            }
-#pragma unroll
-        for (int t = 0; t < BT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * bt_i[t] + 4 * q4 + r, uc = 16 * bt_j[t] + c;
-                int idx = R_ZERO;
-                if (uc < 18 && row == uc) idx = R_DT2;
-                // (dt at (v_16, a_16), (v_17, a_17) of tile (2,1) is applied without the matrix pipe, so that the tile's only non-zero
-                //  rows are momentum rows: contraction steps 0, 1)
-                if (uc < 18 && row == uc + 18 && !(bt_i[t] == 2 && bt_j[t] == 1)) idx = R_DT;
-                if (uc >= WF && uc < NU) {
-                    const int f = uc - WF, sr = state_at(row);
-                    if (sr >= 36 && sr < 39 && sr - 36 == f % 3) idx = R_CDT + f / 3;
-                    if (sr >= 39 && sr < 42) idx = R_HF + (sr - 39) * 12 + f;
-                }
-                bIdx[t][r] = idx;
-            }
-        // input-cost tile (1,1): the barrier block of the foot, and the diagonal W_acc / W_cnt_f_reg + reg of (0,0), (1,1)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ur = 16 + 4 * q4 + r, uc = 16 + c;
-            int idx = IPMW - 1;                                  // a slot that holds zero
-            if (ur >= WF && ur < NU && uc >= WF && uc < NU) {
-                const int fr = ur - WF, fc = uc - WF;
-                if (fr / 3 == fc / 3) {
-                    const int ar = fr % 3, ac = fc % 3;
-                    const int sel = (ar == ac) ? ar : (ar + ac == 2) ? 3 : (ar + ac == 3) ? 4 : -1;
-                    if (sel >= 0) idx = IPM_RF + 5 * (fr / 3) + sel;
-                }
-            }
-            rIdx[r] = idx;
-#pragma unroll
-            for (int i = 0; i < UT; ++i) {
-                const int uu = 16 * i + 4 * q4 + r;
-                float w = 0.0f;
-                if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
-                if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
-                rdiag[i][r] = (uu == 16 * i + c && uu < NU) ? w + a.reg : 0.0f;
-                sIdx[i][r] = (c == HX - 32 && uu < NU) ? uu : IPMW - 1;      // S~: the input gradient rides in column HX
-            }
-        }
-    }
     if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
-    // constants of the identity blocks of B~ (see the backward stage): dt^2, on columns 0, 1 of a tile, on rows 0, 1 of a tile
-    // 1 / sqrt of the pivot of a decoupled force input, by component: Huu[j][j] = (W_f_reg + reg) + 0 there (see ldl_pivots)
-    float rs_free[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) rs_free[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
-    const float dt2 = dt * dt;
-    const float dt2_c01 = (c < 2) ? dt2 : 0.0f, dt_c01 = (c < 2) ? dt : 0.0f;
-    const int up_addr = 4 * ((lane + 16) & 63);
-    const int down_addr = 4 * ((lane + 48) & 63);               // the lane one lane row (16 lanes) before this one
-    const float dt_qn0 = (q4 > 0) ? dt : 0.0f;
-    const bool last_row = lane >= 48;
-    const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
-    const float dt_q0 = (q4 == 0) ? dt : 0.0f;
-    const bool hx_col = (c == HX - 32), hx_row = (q4 == HXQ);     // HX = 38: column 6 of tile column 2; row 6 of tile row 2 = lane row 1, register 2
-    // where this lane finds, in the stage record, the defects of its columns (one per tile column) ...
-    int dcolIdx[XT];
-#pragma unroll
-    for (int kk = 0; kk < XT; ++kk) dcolIdx[kk] = R_D + 16 * kk + c;      // (the record holds zeros where no state sits)
-    float dt2_r01[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
-
     bool qp_ok = true;
     // What a backward sweep starts from -- terminal P~ (nine tiles), the records of stages N-1 and N-2, the lower Q~ tiles of stage
     // N-1 -- is the same for every sweep of a call and is requested at the top of the interior-point phase BEFORE it, so that the
@@ -1079,6 +992,101 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     for (int ii = 0; ii < n_sweeps; ++ii) {
         const float tau = use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f;
         if (ii == 0) { write_ipm_terms(tau); wave_sync(); }
+        // Everything below that is derived from the lane index -- the index maps of the tile synthesis, LDS addresses of the layout
+        // changes, masks -- is recomputed at the top of every sweep from a copy of the lane index the optimiser cannot see through:
+        // ~150 integer operations per sweep.  Computed once per kernel (where loop-invariant code motion puts them) these ~100
+        // registers stay live through the forward sweep and the interior-point phase, which then keep their own working set --
+        // the gain rows of the next two stages -- in the accumulation registers and move every element back before use.
+        int lane_opaque = lane;
+        asm volatile("" : "+v"(lane_opaque));
+        const int lane = lane_opaque, q4 = lane >> 4, c = lane & 15;
+        // per-lane constants of the tile synthesis: every element of N~ = A~ - I, B~, R~ and S~ is ONE LDS read at a
+        // precomputed index -- into the stage record (defect, momentum Jacobians, or one of its constant slots 0, dt, dt^2)
+        // or into the stage's row of barrier-modified input terms.  (Lane predicates instead of indices cost an SGPR pair
+        // per element and tile: the loop-invariant masks spilled 626 SGPRs into VGPR lanes.)
+        constexpr int NT = 6, BT = 5;
+        // non-zero tiles of N~: (0,1) (0,2) (1,2) (2,0) (2,1) (2,2) ; of B~: (0,0) (1,0) (1,1) (2,0) (2,1)
+        int nIdx[NT][4], bIdx[BT][4], rIdx[4], sIdx[UT][4];
+        float rdiag[UT][4];
+        {
+            constexpr int nt_i[NT] = {0, 0, 1, 2, 2, 2}, nt_j[NT] = {1, 2, 2, 0, 1, 2};
+            constexpr int bt_i[BT] = {0, 1, 1, 2, 2}, bt_j[BT] = {0, 0, 1, 0, 1};
+    #pragma unroll
+            for (int t = 0; t < NT; ++t)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * nt_i[t] + 4 * q4 + r, col = 16 * nt_j[t] + c;
+                    int idx = R_ZERO;
+                    if (row < 18 && col == row + 18) idx = R_DT;
+                    const int sr = state_at(row);
+                    if (col == HX && sr >= 0) idx = R_D + row;
+                    if (sr >= 39 && sr < 42 && col >= 3 && col < 18) idx = R_HQ + (sr - 39) * 16 + (col - 3);
+                    nIdx[t][r] = idx;
+                }
+    #pragma unroll
+            for (int t = 0; t < BT; ++t)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * bt_i[t] + 4 * q4 + r, uc = 16 * bt_j[t] + c;
+                    int idx = R_ZERO;
+                    if (uc < 18 && row == uc) idx = R_DT2;
+                    // (dt at (v_16, a_16), (v_17, a_17) of tile (2,1) is applied without the matrix pipe, so that the tile's only non-zero
+                    //  rows are momentum rows: contraction steps 0, 1)
+                    if (uc < 18 && row == uc + 18 && !(bt_i[t] == 2 && bt_j[t] == 1)) idx = R_DT;
+                    if (uc >= WF && uc < NU) {
+                        const int f = uc - WF, sr = state_at(row);
+                        if (sr >= 36 && sr < 39 && sr - 36 == f % 3) idx = R_CDT + f / 3;
+                        if (sr >= 39 && sr < 42) idx = R_HF + (sr - 39) * 12 + f;
+                    }
+                    bIdx[t][r] = idx;
+                }
+            // input-cost tile (1,1): the barrier block of the foot, and the diagonal W_acc / W_cnt_f_reg + reg of (0,0), (1,1)
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ur = 16 + 4 * q4 + r, uc = 16 + c;
+                int idx = IPMW - 1;                                  // a slot that holds zero
+                if (ur >= WF && ur < NU && uc >= WF && uc < NU) {
+                    const int fr = ur - WF, fc = uc - WF;
+                    if (fr / 3 == fc / 3) {
+                        const int ar = fr % 3, ac = fc % 3;
+                        const int sel = (ar == ac) ? ar : (ar + ac == 2) ? 3 : (ar + ac == 3) ? 4 : -1;
+                        if (sel >= 0) idx = IPM_RF + 5 * (fr / 3) + sel;
+                    }
+                }
+                rIdx[r] = idx;
+    #pragma unroll
+                for (int i = 0; i < UT; ++i) {
+                    const int uu = 16 * i + 4 * q4 + r;
+                    float w = 0.0f;
+                    if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
+                    if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
+                    rdiag[i][r] = (uu == 16 * i + c && uu < NU) ? w + a.reg : 0.0f;
+                    sIdx[i][r] = (c == HX - 32 && uu < NU) ? uu : IPMW - 1;      // S~: the input gradient rides in column HX
+                }
+            }
+        }
+        // constants of the identity blocks of B~ (see the backward stage): dt^2, on columns 0, 1 of a tile, on rows 0, 1 of a tile
+        // 1 / sqrt of the pivot of a decoupled force input, by component: Huu[j][j] = (W_f_reg + reg) + 0 there (see ldl_pivots)
+        float rs_free[12];
+    #pragma unroll
+        for (int i = 0; i < 12; ++i) rs_free[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
+        const float dt2 = dt * dt;
+        const float dt2_c01 = (c < 2) ? dt2 : 0.0f, dt_c01 = (c < 2) ? dt : 0.0f;
+        const int up_addr = 4 * ((lane + 16) & 63);
+        const int down_addr = 4 * ((lane + 48) & 63);               // the lane one lane row (16 lanes) before this one
+        const float dt_qn0 = (q4 > 0) ? dt : 0.0f;
+        const bool last_row = lane >= 48;
+        const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
+        const float dt_q0 = (q4 == 0) ? dt : 0.0f;
+        const bool hx_col = (c == HX - 32), hx_row = (q4 == HXQ);     // HX = 38: column 6 of tile column 2; row 6 of tile row 2 = lane row 1, register 2
+        // where this lane finds, in the stage record, the defects of its columns (one per tile column) ...
+        int dcolIdx[XT];
+    #pragma unroll
+        for (int kk = 0; kk < XT; ++kk) dcolIdx[kk] = R_D + 16 * kk + c;      // (the record holds zeros where no state sits)
+        float dt2_r01[4];
+    #pragma unroll
+        for (int r = 0; r < 4; ++r) dt2_r01[r] = (4 * q4 + r < 2) ? dt2 : 0.0f;
+
         // ------------------------------------------------------------ phase R: backward sweep
         // (terminal P~, the records of stages N-1 and N-2 and the Q~ tiles of stage N-1 were requested by request_sweep())
         // record of stage N-1 into the LDS; each stage prefetches the next one's (global -> registers -> LDS)
