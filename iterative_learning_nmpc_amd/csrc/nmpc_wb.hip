@@ -1506,8 +1506,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // du = K~ dx~ row per lane, dx+ from the model's sparse structure -- with dx~ and the force part of du WAVE-UNIFORM in
         // scalar registers (v_readlane broadcasts) and the two lane-shifted terms of the kinematic rows through one crossbar
         // move: no LDS round trip on the stage-to-stage chain (the version that kept dx~, du in the LDS spent 4.4 k cycles
-        // per stage in three dependent write -> fence -> read trips; this one is bit-identical to it).  Gain rows are
-        // requested FWD_PF stages ahead in a register ring, the stage record two stages ahead (registers -> LDS).
+        // per stage in three dependent write -> fence -> read trips; this one is bit-identical to it).  Gain tiles are
+        // requested three stages ahead (registers -> LDS -> rows), the stage record two stages ahead (registers -> LDS).
         float* oX = use_ipm ? dXp : dX;
         float* oU = use_ipm ? dUp : dU;
         // lanes are POSITIONS of x~ (pos_of): lane p holds dx of the state that sits there, lane HX the homogeneous 1, the others 0
@@ -1516,40 +1516,49 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         if (sl >= 0) xcur = x0[sl >= 0 ? sl : 0] - Xg[sl >= 0 ? sl : 0];          // node 0 is not moved by the warm-start shift
         if (lane == HX) xcur = 1.0f;
         if (sl >= 0) AT(oX, 0, sl) = xcur;
-        float* const rbuf[2] = {recb, hbuf};                // stage records, double-buffered (hbuf is free in this phase)
+        float* const rbuf[2] = {recb, hbuf + 1024};         // stage records, double-buffered (hbuf is free in this phase)
+        // The gain images K~' (states x inputs) come in as TILES -- six 16 B loads per lane and stage, every one a contiguous KiB
+        // across the wave -- two stages before the stage that writes them into the LDS (column stride 20 floats: conflict-free),
+        // where every lane reads its row of K~ (a column of K~') a stage later.  A lane reading its row straight from memory
+        // (twelve 16 B loads, 64 B apart between lanes: 64 separate lines per instruction) kept the CU's address path busy for
+        // most of a stage with all four waves in this phase, and a deeper prefetch made that worse, not better.
+        constexpr int KLD = 20, KBUF = UT * XT * 16 * KLD;
+        static_assert(KBUF <= 32 * LDU + 1024 && 1024 + 256 <= 48 * LDH, "gain tiles and the second record buffer fit the elimination's LDS");
+        float* const kbuf = colU;                           // (spans colU and the head of hbuf: both free in this phase)
         const unsigned rec_lane = (4 * lane < REC) ? 4 * lane : 0;
         auto load_rec = [&](int k) { return *reinterpret_cast<const f32x4*>(recs + (size_t)(k < N ? k : N - 1) * REC + rec_lane); };
         *reinterpret_cast<f32x4*>(rbuf[0] + 4 * lane) = load_rec(0);
         f32x4 rec_ahead = load_rec(1);                      // the record of stage k + 1 while stage k runs
         wave_sync();
         const int urow = lane < NU ? lane : 0;
-        // the gain images hold K~' (states x inputs, column-major): row `urow` of K~ is one contiguous column per state tile,
-        // eleven 16 B loads + one of 8 B per lane instead of 43 dwords (the CU's address path takes 16 cycles per wave-instruction)
-        const unsigned krow_off = (unsigned)((urow >> 4) * XT * IMG + (urow & 15) * TS);
-        auto load_krow = [&](int k, float (&row)[XW]) {
-            const float* Kk = Kimg + (size_t)(k < N ? k : N - 1) * KT_FLOATS + krow_off;
+        auto load_ktiles = [&](int k, f32x4 (&t)[UT * XT]) {
+            const float* Kk = Kimg + (size_t)(k < N ? k : N - 1) * KT_FLOATS;
 #pragma unroll
-            for (int j4 = 0; j4 < 11; ++j4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(Kk + (j4 >> 2) * IMG + 4 * (j4 & 3));
+            for (int i = 0; i < UT * XT; ++i) t[i] = load_tile(Kk + i * IMG, lane);
+        };
+        auto put_ktiles = [&](const f32x4 (&t)[UT * XT]) {
+#pragma unroll
+            for (int i = 0; i < UT * XT; ++i) *reinterpret_cast<f32x4*>(kbuf + (i * 16 + c) * KLD + 4 * q4) = t[i];
+        };
+        const float* const krow = kbuf + ((urow >> 4) * XT * 16 + (urow & 15)) * KLD;      // tiles (urow >> 4, 0..2), column urow & 15
+        auto get_krow = [&](float (&row)[48]) {
+#pragma unroll
+            for (int j4 = 0; j4 < 12; ++j4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(krow + (j4 >> 2) * 16 * KLD + 4 * (j4 & 3));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) row[4 * j4 + r] = v[r];
             }
-            // positions 44, 45 as 8 bytes, and EVERY loaded element is used below (the padding positions meet dx~ = 0): an unused
-            // register of a 16 B load is free for reuse at once, and whatever is written to it next waits for the load to land
-            // (write after write) -- that wait sat in the middle of the NEXT stage, behind all the row loads issued before it
-            // (vmcnt retires in order), and undid the prefetch
-            const f32x2 v2 = *reinterpret_cast<const f32x2*>(Kk + 2 * IMG + 12);
-            row[44] = v2[0]; row[45] = v2[1];
-            static_assert(XW == 46, "row tail");
         };
         const int fi = sl >= 0 ? sl : 0;
         const int hr = (fi >= 39) ? fi - 39 : 0, lr = (fi >= 36 && fi < 39) ? fi - 36 : 0;
         const int x_addr = 4 * (lane < 18 ? lane + 18 : (lane < 36 ? lane - 18 : lane));      // q rows take dx of their v row, v rows du of their q row
-        constexpr int FWD_PF = 2;
-        float ring[FWD_PF][XW];
-#pragma unroll
-        for (int pf = 0; pf < FWD_PF; ++pf) load_krow(pf, ring[pf]);
-        auto fwd_stage = [&](int k, float (&row)[XW]) {
+        f32x4 ktA[UT * XT], ktB[UT * XT];                   // tiles on their way: requested two stages before their LDS write
+        load_ktiles(0, ktA);
+        load_ktiles(1, ktB);
+        put_ktiles(ktA);
+        load_ktiles(2, ktA);
+        wave_sync();
+        auto fwd_stage = [&](int k, f32x4 (&kt)[UT * XT]) {      // kt: the tiles of stage k + 1, refilled with those of k + 3
             const float* rk = rbuf[k & 1];
             const f32x4 rec_next = rec_ahead;                // stage k + 1's record, requested a stage ago
             rec_ahead = load_rec(k + 2);
@@ -1561,6 +1570,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int v4 = 0; v4 < 3; ++v4) hf4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12 + 4 * v4);
             const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
+            float row[48];
+            get_krow(row);
             float dxs[XW];
 #pragma unroll
             for (int j = 0; j < XW; ++j) dxs[j] = bcast(xcur, j);
@@ -1573,7 +1584,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 if (4 * j4 + 3 < XW) a3 = fmaf(row[4 * j4 + 3 < XW ? 4 * j4 + 3 : 0], dxs[4 * j4 + 3 < XW ? 4 * j4 + 3 : 0], a3);
             }
             const float du = (a0 + a1) + (a2 + a3);
-            load_krow(k + FWD_PF, row);                      // refill the ring slot after its last use
             WB_STAMP(13);
             if (lane < NU) AT(oU, k, lane) = du;
             float duf[12];
@@ -1607,18 +1617,18 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             if (sl >= 0) AT(oX, k + 1, sl) = xn;
             xcur = (sl >= 0) ? xn : (lane == HX ? 1.0f : 0.0f);
             *reinterpret_cast<f32x4*>(rbuf[(k + 1) & 1] + 4 * lane) = rec_next;
+            put_ktiles(kt);                                  // (this stage's row reads were issued before: the LDS serves a wave in order)
+            load_ktiles(k + 3, kt);
             wave_sync();
             WB_STAMP(15);
         };
         {
             int k = 0;
-            for (; k + FWD_PF <= N; k += FWD_PF) {
-#pragma unroll
-                for (int pf = 0; pf < FWD_PF; ++pf) fwd_stage(k + pf, ring[pf]);
+            for (; k + 2 <= N; k += 2) {
+                fwd_stage(k, ktB);
+                fwd_stage(k + 1, ktA);
             }
-#pragma unroll
-            for (int pf = 0; pf < FWD_PF - 1; ++pf)
-                if (k + pf < N) fwd_stage(k + pf, ring[pf]);
+            if (k < N) fwd_stage(k, ktB);
         }
         phase_sync();
         WB_STAMP(9);
@@ -1657,6 +1667,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             blend_request(lane);
 #pragma unroll
             for (int i = 0; i < NU; ++i) rr[i] = more ? rec[R_R + i] : 0.0f;
+            request_sweep();
             gdot(mp, duf, g);
             // (the steps ds, dl are formed twice -- for the step lengths and for the update -- rather than kept: 32 registers)
             float rp = 0.0f, rd = 0.0f;
@@ -1698,7 +1709,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
             // (no fence here: the next reader of dX, dU across lanes is the step phase, behind its own phase_sync; the slacks and
             //  multipliers are read back by the lane that wrote them)
-            request_sweep();      // (unconditionally: defined on every path round the loop, it holds no register through the other phases)
             if (more) {
                 ipm_terms(fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min), s, l, cc, rr);
                 wave_sync();
