@@ -254,8 +254,11 @@ class SolveSetup:
                            "nmpc_qp_kernel<Centroidal> (+ nmpc_linearize_kernel, 5 % of the solve call)"), "kernel_ms": kernel_ms,
                 "flops_per_solve": flops, "bytes_per_solve": nbytes,
                 "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
-                "binds": "instruction issue of one wave per SIMD along the serial stage recursion (MFMA + VALU + LDS of a wave "
-                         "do not overlap; profiles/): neither HBM nor the MFMA peak"}
+                "binds": ("backward sweeps: instruction issue of one wave per SIMD along the serial stage recursion (154 MFMAs + the "
+                          "elimination's dependent chain per stage); forward sweeps: what memory delivers for the stage images "
+                          "(3.4 TB/s of counter traffic over the launch, see traffic_over_algorithmic: DESIGN.md 5b (18))" if self.wbm else
+                          "instruction issue of one wave per SIMD along the serial stage recursion (MFMA + VALU + LDS of a wave "
+                          "do not overlap; profiles/): neither HBM nor the MFMA peak")}
 
 
 def timed_steps(setup, steps, warmup, dist=None, exchange=None, ramp=0.25):
