@@ -457,14 +457,22 @@ constexpr int LDH = 52;      // LDS column stride of the 48-row transposition bu
 constexpr int IPMW = 57;     // LDS row of a stage's barrier-modified input terms: rt[30] at 0, Rf[4][5] at 32
 constexpr int IPM_RF = 32;
 
+constexpr int KLD = 20;                      // LDS column stride of a gain tile K~' (conflict-free 16 B row reads)
+constexpr int KBUF = UT * XT * 16 * KLD;     // the six tiles of one stage
 struct WbLds {
-    int colU, hbuf, recb, ipm, total;
+    int colU, hbuf, recb, ipm, klds, n_klds, total;
     __host__ __device__ explicit WbLds(int N) {
         int o = 0;
         colU = o; o += NG * 0 + 32 * LDU;
         hbuf = o; o += 48 * LDH;
         recb = o; o += 256;
         ipm = o;  o += r4(N * IPMW);
+        // the gains of the LAST stages of a backward sweep (the first of the forward sweep) stay in the LDS -- as many as fit next to
+        // three other waves of the CU (160 KB / 4): the forward sweep starts without a trip to memory and those images never leave the CU
+        klds = o;
+        n_klds = (o + 2 * KBUF) * 4 <= 40 * 1024 ? 2 : (o + KBUF) * 4 <= 40 * 1024 ? 1 : 0;
+        if (n_klds > N) n_klds = N;
+        o += n_klds * KBUF;
         total = o;
     }
 };
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     float* dXp = arr + SA.dXp; float* dUp = arr + SA.dUp;
     float* sv = arr + SA.sv;   float* lv = arr + SA.lv;
     float* colU = smem + L.colU; float* hbuf = smem + L.hbuf;
-    float* recb = smem + L.recb; float* ipm = smem + L.ipm;
+    float* recb = smem + L.recb; float* ipm = smem + L.ipm; float* klds = smem + L.klds;
     const float* recs = ws + wl.rec;
     float* Qimg = ws + wl.qt;
     float* Kimg = ws + wl.kt;
@@ -1495,7 +1503,8 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #ifdef WB_T_NOKSTORE     // timing build (tools/ab_wb.sh): no gain stores -- results are wrong, the time tells what the stores cost
                         if (a.B < 0)
 #endif
-                        store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
+                        if (k >= L.n_klds) store_tile(Kimg + (size_t)k * KT_FLOATS + (i * XT + j) * IMG, lane, Kt[i][j]);
+                        else *reinterpret_cast<f32x4*>(klds + k * KBUF + ((i * XT + j) * 16 + c) * KLD + 4 * q4) = Kt[i][j];
                     }
             }
             WB_STAMP(18);      // K~ products and stores
@@ -1522,7 +1531,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // where every lane reads its row of K~ (a column of K~') a stage later.  A lane reading its row straight from memory
         // (twelve 16 B loads, 64 B apart between lanes: 64 separate lines per instruction) kept the CU's address path busy for
         // most of a stage with all four waves in this phase, and a deeper prefetch made that worse, not better.
-        constexpr int KLD = 20, KBUF = UT * XT * 16 * KLD;
         static_assert(KBUF <= 32 * LDU + 1024 && 1024 + 256 <= 48 * LDH, "gain tiles and the second record buffer fit the elimination's LDS");
         float* const kbuf = colU;                           // (spans colU and the head of hbuf: both free in this phase)
         const unsigned rec_lane = (4 * lane < REC) ? 4 * lane : 0;
@@ -1540,8 +1548,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int i = 0; i < UT * XT; ++i) *reinterpret_cast<f32x4*>(kbuf + (i * 16 + c) * KLD + 4 * q4) = t[i];
         };
-        const float* const krow = kbuf + ((urow >> 4) * XT * 16 + (urow & 15)) * KLD;      // tiles (urow >> 4, 0..2), column urow & 15
-        auto get_krow = [&](float (&row)[48]) {
+        const int krow_off = ((urow >> 4) * XT * 16 + (urow & 15)) * KLD;      // tiles (urow >> 4, 0..2), column urow & 15
+        auto get_krow = [&](const float* buf, float (&row)[48]) {
+            const float* krow = buf + krow_off;
 #pragma unroll
             for (int j4 = 0; j4 < 12; ++j4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(krow + (j4 >> 2) * 16 * KLD + 4 * (j4 & 3));
@@ -1552,11 +1561,22 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         const int fi = sl >= 0 ? sl : 0;
         const int hr = (fi >= 39) ? fi - 39 : 0, lr = (fi >= 36 && fi < 39) ? fi - 36 : 0;
         const int x_addr = 4 * (lane < 18 ? lane + 18 : (lane < 36 ? lane - 18 : lane));      // q rows take dx of their v row, v rows du of their q row
-        f32x4 ktA[UT * XT], ktB[UT * XT];                   // tiles on their way: requested two stages before their LDS write
-        load_ktiles(0, ktA);
-        load_ktiles(1, ktB);
-        put_ktiles(ktA);
-        load_ktiles(2, ktA);
+        // tiles on their way: requested two stages before their LDS write.  ktA holds those of the even stages, ktB of the odd ones;
+        // the first n_klds stages find their gains in the LDS where the backward sweep left them
+        f32x4 ktA[UT * XT], ktB[UT * XT];
+        const int KL = L.n_klds;                            // 0, 1 or 2
+        if (KL == 0) {
+            load_ktiles(0, ktA);
+            load_ktiles(1, ktB);
+            put_ktiles(ktA);
+            load_ktiles(2, ktA);
+        } else if (KL == 1) {
+            load_ktiles(1, ktB);
+            load_ktiles(2, ktA);
+        } else {
+            load_ktiles(2, ktA);
+            load_ktiles(3, ktB);
+        }
         wave_sync();
         auto fwd_stage = [&](int k, f32x4 (&kt)[UT * XT]) {      // kt: the tiles of stage k + 1, refilled with those of k + 3
             const float* rk = rbuf[k & 1];
@@ -1571,7 +1591,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             for (int v4 = 0; v4 < 3; ++v4) hf4[v4] = *reinterpret_cast<const f32x4*>(rk + R_HF + hr * 12 + 4 * v4);
             const f32x4 cd = *reinterpret_cast<const f32x4*>(rk + R_CDT);
             float row[48];
-            get_krow(row);
+            get_krow(k < KL ? klds + k * KBUF : kbuf, row);
             float dxs[XW];
 #pragma unroll
             for (int j = 0; j < XW; ++j) dxs[j] = bcast(xcur, j);
@@ -1617,8 +1637,10 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             if (sl >= 0) AT(oX, k + 1, sl) = xn;
             xcur = (sl >= 0) ? xn : (lane == HX ? 1.0f : 0.0f);
             *reinterpret_cast<f32x4*>(rbuf[(k + 1) & 1] + 4 * lane) = rec_next;
-            put_ktiles(kt);                                  // (this stage's row reads were issued before: the LDS serves a wave in order)
-            load_ktiles(k + 3, kt);
+            if (k + 1 >= KL) {
+                put_ktiles(kt);                              // (this stage's row reads were issued before: the LDS serves a wave in order)
+                load_ktiles(k + 3, kt);
+            }
             wave_sync();
             WB_STAMP(15);
         };
