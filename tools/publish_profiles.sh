@@ -2,6 +2,8 @@
 # gpurun_out/prof_<tag>_* (tools/profile_all.sh) -> the summaries committed under profiles/ and profiles/traffic.json
 #   tools/publish_profiles.sh r03
 set -euo pipefail
+# (gpurun MERGES a call's files into gpurun_out/: after a second profile run of the same tag, delete the older run's files first --
+#  find gpurun_out/prof_<tag>_* -type f -mmin +N -delete -- or the summaries average two builds)
 tag="$1"
 python tools/summarize_profile.py gpurun_out/prof_${tag}_c profiles/${tag}_solve_b1024.md nmpc_qp_kernel > /dev/null
 python tools/summarize_profile.py gpurun_out/prof_${tag}_c8k profiles/${tag}_solve_b8192.md nmpc_qp_kernel > /dev/null
