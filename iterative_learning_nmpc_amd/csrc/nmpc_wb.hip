@@ -979,6 +979,20 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     };
 
     if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
+    // the weight-derived constants of the backward sweep (loads from the argument block: once per kernel, unlike the index maps)
+    float rdiag_w[UT][4], rs_free_w[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < UT; ++i) {
+            const int uu = 16 * i + 4 * q4 + r;
+            float w = 0.0f;
+            if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
+            if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
+            rdiag_w[i][r] = (uu == 16 * i + c && uu < NU) ? w + a.reg : 0.0f;
+        }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) rs_free_w[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
     bool qp_ok = true;
     // What a backward sweep starts from -- terminal P~ (nine tiles), the records of stages N-1 and N-2, the lower Q~ tiles of stage
     // N-1 -- is the same for every sweep of a call and is requested at the top of the interior-point phase BEFORE it, so that the
@@ -1065,10 +1079,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     #pragma unroll
                 for (int i = 0; i < UT; ++i) {
                     const int uu = 16 * i + 4 * q4 + r;
-                    float w = 0.0f;
-                    if (uu >= 6 && uu < 18) w = a.W[RY_ACC + (uu >= 6 && uu < 18 ? uu - 6 : 0)];
-                    if (uu >= WF && uu < NU) w = a.W[RY_FREG + (uu >= WF && uu < NU ? uu - WF : 0)];
-                    rdiag[i][r] = (uu == 16 * i + c && uu < NU) ? w + a.reg : 0.0f;
+                    rdiag[i][r] = rdiag_w[i][r];
                     sIdx[i][r] = (c == HX - 32 && uu < NU) ? uu : IPMW - 1;      // S~: the input gradient rides in column HX
                 }
             }
@@ -1077,7 +1088,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // 1 / sqrt of the pivot of a decoupled force input, by component: Huu[j][j] = (W_f_reg + reg) + 0 there (see ldl_pivots)
         float rs_free[12];
     #pragma unroll
-        for (int i = 0; i < 12; ++i) rs_free[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
+        for (int i = 0; i < 12; ++i) rs_free[i] = rs_free_w[i];
         const float dt2 = dt * dt;
         const float dt2_c01 = (c < 2) ? dt2 : 0.0f, dt_c01 = (c < 2) ? dt : 0.0f;
         const int up_addr = 4 * ((lane + 16) & 63);
@@ -1671,11 +1682,11 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int j = 0; j < NG; ++j) { cc[j] = rec[R_C + j]; s[j] = ld_f32(sv + j * NS, k4, 0); l[j] = ld_f32(lv + j * NS, k4, 0); }
             // step <- step + ap (new step - step): [dX | dU] and [dXp | dUp] have the same layout (StageArr), one pass over both
-            // in 16 B pieces, five pieces per lane in flight
+            // in 16 B pieces, nine pieces per lane in flight
             const int nvec = (SA.dXp - SA.dX) >> 2;
             f32x4* d4 = reinterpret_cast<f32x4*>(dX);
             const f32x4* n4 = reinterpret_cast<const f32x4*>(dXp);
-            constexpr int BL = 5;
+            constexpr int BL = 9;      // N <= 30: the whole blend in one round (559 pieces)
             f32x4 dv[BL], nv[BL];
             auto blend_request = [&](int i0) {
 #pragma unroll
@@ -1702,6 +1713,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 rp = on ? fmaxf(rp, -dsj * is) : rp;
                 rd = on ? fmaxf(rd, -dlj * __builtin_amdgcn_rcpf(l[j])) : rd;
             }
+            WB_STAMP(22);      // inputs arrived, step lengths per lane
             const float rpm = wave_max(rp), rdm = wave_max(rd);
             const float ap = rpm > a.gamma ? a.gamma / rpm : 1.0f;
             const float ad = rdm > a.gamma ? a.gamma / rdm : 1.0f;
@@ -1721,6 +1733,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 for (int j = 0; j < NG; ++j) { st_f32(sv + j * NS, k4, 0, s[j]); st_f32(lv + j * NS, k4, 0, l[j]); }
             }
             mu_sum = wave_sum(m_l);
+            WB_STAMP(23);      // reductions, update, slack / multiplier stores
             for (int i0 = lane; i0 < nvec; i0 += 64 * BL) {
 #pragma unroll
                 for (int u = 0; u < BL; ++u) {

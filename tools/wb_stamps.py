@@ -25,4 +25,4 @@ for n, v in zip(names, m):
 print(f"  loop back edge (slot 19) {m[19] / 180:.0f} per stage; interior-point phase of every sweep (slot 20) {m[20]:.0f} per solve = {m[20] / 180:.0f} per stage; sweep set-up (slot 21) {m[21]:.0f} per solve = {m[21] / 180:.0f} per stage")
 print(f"  tail of the backward stage (slots 16-18; slot 0 then holds the loop top only): P+ products {m[16] / 180:.0f}, mirror {m[17] / 180:.0f}, K products + stores {m[18] / 180:.0f}, loop top {m[0] / 180:.0f} per stage")
 print(f"  forward stage split (separate slots, not in the table's 'forward sweeps'): du = K dx {m[13] / 180:.0f}, dx+ {m[14] / 180:.0f}, hand-over {m[15] / 180:.0f} per stage")
-print(f"  forward stage, finer (slots 22, 23, 13): record reads {m[22] / 180:.0f}, dx~ broadcasts {m[23] / 180:.0f}, row products + next rows requested {m[13] / 180:.0f} per stage")
+print(f"  interior-point phase, finer (slots 22, 23, 20; per sweep): inputs + step lengths {m[22] / 6:.0f}, reductions + update + stores {m[23] / 6:.0f}, blend + barrier terms {m[20] / 6:.0f}")
