@@ -1589,7 +1589,27 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             load_ktiles(3, ktB);
         }
         wave_sync();
+        // What the interior-point phase reads that this sweep does not write -- slacks, multipliers, constraint values, the input
+        // gradient of the next sweep's barrier terms, lane = stage -- is requested three stages before the sweep ends: the phase then
+        // opens with its inputs in registers instead of a trip to memory (7 k cycles per sweep).
+        const bool ipm_more = ii + 1 < n_sweeps;
+        const int ipm_k = lane < N ? lane : 0;
+        float ipm_s[NG], ipm_l[NG], ipm_c[NG], ipm_rr[NU];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) ipm_s[j] = ipm_l[j] = ipm_c[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) ipm_rr[i] = 0.0f;
+        auto request_ipm_inputs = [&]() {
+            const unsigned k4 = 4u * (unsigned)ipm_k;
+            const float* rec = recs + (size_t)ipm_k * REC;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { ipm_c[j] = rec[R_C + j]; ipm_s[j] = ld_f32(sv + j * NS, k4, 0); ipm_l[j] = ld_f32(lv + j * NS, k4, 0); }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ipm_rr[i] = ipm_more ? rec[R_R + i] : 0.0f;
+        };
+        const int ipm_request_stage = N > 3 ? N - 3 : 0;
         auto fwd_stage = [&](int k, f32x4 (&kt)[UT * XT]) {      // kt: the tiles of stage k + 1, refilled with those of k + 3
+            if (use_ipm && k == ipm_request_stage) request_ipm_inputs();
             const float* rk = rbuf[k & 1];
             const f32x4 rec_next = rec_ahead;                // stage k + 1's record, requested a stage ago
             rec_ahead = load_rec(k + 2);
@@ -1671,16 +1691,14 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         // serially (load, compute, store, fence, load ...) the phase took six memory latencies per sweep, 15 % of the kernel
         // (tools/wb_stamps.py, slot 20).  Addresses are uniform base + lane offset (one VGPR for all of them).
         if (use_ipm) {
-            const bool more = ii + 1 < n_sweeps;
+            const bool more = ipm_more;
             const bool live = lane < N;
-            const int k = live ? lane : 0;
+            const int k = ipm_k;
             const unsigned k4 = 4u * (unsigned)k;
-            const float* rec = recs + (size_t)k * REC;
-            float duf[12], g[NG], s[NG], l[NG], cc[NG], rr[NU];
+            float duf[12], g[NG];
+            float (&s)[NG] = ipm_s; float (&l)[NG] = ipm_l; float (&cc)[NG] = ipm_c; float (&rr)[NU] = ipm_rr;
 #pragma unroll
             for (int i = 0; i < 12; ++i) duf[i] = ld_f32(dUp + (WF + i) * NS, k4, 0);
-#pragma unroll
-            for (int j = 0; j < NG; ++j) { cc[j] = rec[R_C + j]; s[j] = ld_f32(sv + j * NS, k4, 0); l[j] = ld_f32(lv + j * NS, k4, 0); }
             // step <- step + ap (new step - step): [dX | dU] and [dXp | dUp] have the same layout (StageArr), one pass over both
             // in 16 B pieces, nine pieces per lane in flight
             const int nvec = (SA.dXp - SA.dX) >> 2;
@@ -1698,8 +1716,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                 }
             };
             blend_request(lane);
-#pragma unroll
-            for (int i = 0; i < NU; ++i) rr[i] = more ? rec[R_R + i] : 0.0f;
             request_sweep();
             gdot(mp, duf, g);
             // (the steps ds, dl are formed twice -- for the step lengths and for the update -- rather than kept: 32 registers)
