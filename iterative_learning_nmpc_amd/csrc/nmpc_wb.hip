@@ -47,10 +47,66 @@ static_assert(pos_of(36) == 36 && pos_of(37) == 37 && pos_of(38) == 40 && pos_of
 static_assert(state_at(40) == 38 && state_at(45) == 41 && state_at(HX) == -1 && state_at(39) == -1 && state_at(46) == -1, "momentum slots");
 constexpr int HXQ = (HX - 32) >> 2, HXR = (HX - 32) & 3;      // lane row and register of row HX in tile row 2
 static_assert(HXR == 2, "the homogeneous row is register 2 of its lane row");
+
+// ---- the scaled residual Jacobian Js = sqrt(W) [J | res] of a node, COMPACT -------------------------------------------------------
+// Js is 30 x 46 with 381 structural non-zeros.  As a dense tile image (6 KB per node, each thread of the linearisation scattering
+// its ~440 dword stores over its own image) it cost 0.6 of the linearisation's 0.78 ms per launch; it is now a 388-float record
+// in the order the linearisation produces it, written in 16 B pieces, and the QP kernel's prologue gathers its operand tiles
+// from the record through a per-lane index map (cj_index) -- the way the stage sweeps synthesise N~ and B~.
+//   foot f, floats 88 f ..:  contact rows 3f+i (i < 3):  [6 c + i]      column q(xi_c)       c < 9  (xi = [r, theta, ql_f])
+//                                                        [6 c + 3 + i]  column v(xi_c)
+//                                                        [54 + i]       column HX (the scaled residual)
+//                            swing row 12+f:             [57 + c], [66] column HX            ([67] padding)
+//                            placement rows 22+2f+i:     [68 + 10 i + c], [68 + 10 i + 9] column HX
+//   consistency, floats 352 ..:  rows 16+i: [3 i] h_lin_i, [3 i + 1] v_i, [3 i + 2] HX;  rows 19+i: [9 + 2 i] h_ang_i, [10 + 2 i] HX,
+//                                [15 + 3 a + i] theta_a, [24 + 3 a + i] thetadot_a            ([33..35] padding)
+constexpr int CJ_FOOT = 88, CJ_CONS = 4 * CJ_FOOT, CJ_FLOATS = CJ_CONS + 36;
+constexpr int JS_FLOATS = CJ_FLOATS;
+static_assert(CJ_FLOATS % 4 == 0, "records are whole 16 B pieces");
+__host__ __device__ constexpr int xi_slot(int f, int qi) {      // inverse of xi_col: slot of coordinate qi in xi_f, or -1
+    return qi < 6 ? qi : (qi >= 6 + 3 * f && qi < 9 + 3 * f) ? 6 + (qi - 6 - 3 * f) : -1;
+}
+// record index of element (row, column POSITION) of Js, or -1 for a structural zero
+__host__ __device__ constexpr int cj_index(int row, int col) {
+    if (row < 12) {
+        const int f = row / 3, i = row % 3;
+        if (col == HX) return CJ_FOOT * f + 54 + i;
+        if (col < 18) { const int c = xi_slot(f, col); return c < 0 ? -1 : CJ_FOOT * f + 6 * c + i; }
+        if (col < 36) { const int c = xi_slot(f, col - 18); return c < 0 ? -1 : CJ_FOOT * f + 6 * c + 3 + i; }
+        return -1;
+    }
+    if (row < 16) {
+        const int f = row - 12;
+        if (col == HX) return CJ_FOOT * f + 66;
+        if (col < 18) { const int c = xi_slot(f, col); return c < 0 ? -1 : CJ_FOOT * f + 57 + c; }
+        return -1;
+    }
+    if (row < 19) {
+        const int i = row - 16;
+        return col == pos_of(WH + i) ? CJ_CONS + 3 * i : col == WV + i ? CJ_CONS + 3 * i + 1 : col == HX ? CJ_CONS + 3 * i + 2 : -1;
+    }
+    if (row < 22) {
+        const int i = row - 19;
+        if (col == pos_of(WH + 3 + i)) return CJ_CONS + 9 + 2 * i;
+        if (col == HX) return CJ_CONS + 10 + 2 * i;
+        if (col >= WQ + 3 && col < WQ + 6) return CJ_CONS + 15 + 3 * (col - WQ - 3) + i;
+        if (col >= WV + 3 && col < WV + 6) return CJ_CONS + 24 + 3 * (col - WV - 3) + i;
+        return -1;
+    }
+    if (row < 30) {
+        const int f = (row - 22) / 2, i = (row - 22) % 2;
+        if (col == HX) return CJ_FOOT * f + 68 + 10 * i + 9;
+        if (col < 18) { const int c = xi_slot(f, col); return c < 0 ? -1 : CJ_FOOT * f + 68 + 10 * i + c; }
+        return -1;
+    }
+    return -1;
+}
+static_assert(cj_index(0, 0) == 0 && cj_index(5, 18 + 9) == CJ_FOOT + 6 * 6 + 3 + 2 && cj_index(4, 6) == -1 && cj_index(13, HX) == CJ_FOOT + 66, "cj_index");
+static_assert(cj_index(17, pos_of(WH + 1)) == CJ_CONS + 3 && cj_index(20, WV + 4) == CJ_CONS + 24 + 3 + 1 && cj_index(29, 2) == CJ_FOOT * 3 + 68 + 10 + 2, "cj_index");
 constexpr int XT = 3, UT = 2;          // 16-wide tiles of the state (48) and input (32) dimensions
 constexpr int JT = 2;                  // K tiles of the dense residual Jacobian (22 rows)
 constexpr int IMG = TILE;              // floats of one tile image (column-major 16x16)
-constexpr int JS_FLOATS = JT * XT * IMG, QT_FLOATS = XT * XT * IMG, KT_FLOATS = UT * XT * IMG;
+constexpr int QT_FLOATS = XT * XT * IMG, KT_FLOATS = UT * XT * IMG;
 
 // per-node record written by the linearisation (float offsets)
 constexpr int R_D = 0;                 // defect d, by POSITION: [48], zero where no state sits
@@ -198,11 +254,11 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         base_rotation<true>(th, thd, br);
     }
     float cost = 0.0f;
-    // element (row, col) of the scaled residual Jacobian image; col = POSITION of the state (pos_of), HX = scaled residual value
-    auto put_js = [&](int row, int col, float v) { js[((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)] = v; };
-    auto put_js3 = [&](int row, int col, float v0, float v1, float v2) {       // rows row .. row + 2 of one tile
-        typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-        *reinterpret_cast<f32x3u*>(js + ((row >> 4) * XT + (col >> 4)) * IMG + (col & 15) * TS + (row & 15)) = f32x3u{v0, v1, v2};
+    // a run of the node's compact Jacobian record (layout: cj_index), from registers, in 16 B pieces
+    float* cj = static_cast<float*>(__builtin_assume_aligned(js, 16));
+    auto put_cj = [&](int off, int n, const float* v) {
+#pragma unroll
+        for (int i = 0; i < n; i += 4) *reinterpret_cast<f32x4*>(cj + off + i) = f32x4{v[i], v[i + 1], v[i + 2], v[i + 3]};
     };
 
     // a run of the record, from registers, in 16 B pieces (`off` a multiple of four)
@@ -261,6 +317,8 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
         // foot-placement rows (pos_cost, solver.py:128-137,272-273): world x, y of the foot - planned location.  Weight 0
         // outside the contact-restricted mode: the rows are then exact zeros in the image and are not rewritten
         // (a.pos_rows, wave-uniform; nmpc_set_weights has the image cleared when the rows go from weighted to unweighted)
+        float fb[CJ_FOOT];      // this foot's part of the compact Jacobian record
+        fb[67] = 0.0f;
         if (a.pos_rows) {
             const float px[2] = {x[WQ] + Rb[0], x[WQ + 1] + Rb[1]};
 #pragma unroll
@@ -269,9 +327,10 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                 const float res = px[i] - yr[r_ps + 2 * f + i];
                 cost += 0.5f * w * res * res;
 #pragma unroll
-                for (int c = 0; c < 9; ++c) put_js(22 + 2 * f + i, WQ + xi_col(f, c), sw * J[i][c]);
-                put_js(22 + 2 * f + i, HX, sw * res);
+                for (int c = 0; c < 9; ++c) fb[68 + 10 * i + c] = sw * J[i][c];
+                fb[68 + 10 * i + 9] = sw * res;
             }
+            put_cj(CJ_FOOT * f + 68, 20, fb + 68);
         }
         // swing row: peak z_foot - ref
         {
@@ -279,11 +338,10 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
             const float res = peak * pz - yr[r_sw + f];
             cost += 0.5f * w * res * res;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) put_js(12 + f, WQ + xi_col(f, c), sw * peak * J[2][c]);
-            put_js(12 + f, HX, sw * res);
+            for (int c = 0; c < 9; ++c) fb[57 + c] = sw * peak * J[2][c];
+            fb[66] = sw * res;
         }
-        // contact rows: c (J v + p_gain e_z (z - plane_z)) - ref.  The three rows of a foot are neighbours in a column of the
-        // image: one 12 B store per column instead of three dwords
+        // contact rows: c (J v + p_gain e_z (z - plane_z)) - ref
         {
             float sres[3], swc[3];
 #pragma unroll
@@ -298,11 +356,12 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
             }
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                put_js3(3 * f, WQ + xi_col(f, c), swc[0] * Jd[0][c], swc[1] * Jd[1][c], swc[2] * (Jd[2][c] + mp.p_gain * J[2][c]));
-                put_js3(3 * f, WV + xi_col(f, c), swc[0] * J[0][c], swc[1] * J[1][c], swc[2] * J[2][c]);
+                fb[6 * c + 0] = swc[0] * Jd[0][c]; fb[6 * c + 1] = swc[1] * Jd[1][c]; fb[6 * c + 2] = swc[2] * (Jd[2][c] + mp.p_gain * J[2][c]);
+                fb[6 * c + 3] = swc[0] * J[0][c];  fb[6 * c + 4] = swc[1] * J[1][c];  fb[6 * c + 5] = swc[2] * J[2][c];
             }
-            put_js3(3 * f, HX, sres[0], sres[1], sres[2]);
+            fb[54] = sres[0]; fb[55] = sres[1]; fb[56] = sres[2];
         }
+        put_cj(CJ_FOOT * f, 68, fb);
         if (!term) {   // momentum rows of the dynamics
             const float ff[3] = {u[WF + 3 * f], u[WF + 3 * f + 1], u[WF + 3 * f + 2]};
             float tq[3];
@@ -328,6 +387,8 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
     }
     // ---- consistency rows  h - A_g(q) v,  A_g v = [m rdot ; R I_b E(theta) thetadot]
     {
+        float cb[36];      // the consistency part of the compact Jacobian record
+        cb[33] = cb[34] = cb[35] = 0.0f;
         const float thd[3] = {x[WV + 3], x[WV + 4], x[WV + 5]};
         const float Ib[3] = {mp.ixx, mp.iyy, mp.izz};
         float sy, cy, sx, cx;
@@ -348,16 +409,13 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
                 const float w = Wv[r_cs + i], sw = sqrtf(w);
                 const float res = x[WH + i] - mp.mass * x[WV + i] - yr[r_cs + i];
                 cost += 0.5f * w * res * res;
-                put_js(16 + i, pos_of(WH + i), sw);
-                put_js(16 + i, WV + i, -sw * mp.mass);
-                put_js(16 + i, HX, sw * res);
+                cb[3 * i] = sw; cb[3 * i + 1] = -sw * mp.mass; cb[3 * i + 2] = sw * res;
             }
             {   // angular momentum
                 const float w = Wv[r_cs + 3 + i], sw = sqrtf(w);
                 const float res = x[WH + 3 + i] - L[i] - yr[r_cs + 3 + i];
                 cost += 0.5f * w * res * res;
-                put_js(19 + i, pos_of(WH + 3 + i), sw);
-                put_js(19 + i, HX, sw * res);
+                cb[9 + 2 * i] = sw; cb[10 + 2 * i] = sw * res;
             }
         }
 #pragma unroll
@@ -372,10 +430,11 @@ __global__ __launch_bounds__(64, WB_LIN_WAVES) void nmpc_wb_linearize_kernel(con
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float sw = sqrtf(Wv[r_cs + 3 + i]);
-                put_js(19 + i, WQ + 3 + aa, -sw * (t0[i] + t1[i]));
-                put_js(19 + i, WV + 3 + aa, -sw * t2[i]);
+                cb[15 + 3 * aa + i] = -sw * (t0[i] + t1[i]);
+                cb[24 + 3 * aa + i] = -sw * t2[i];
             }
         }
+        put_cj(CJ_CONS, 36, cb);
     }
     // ---- diagonal residuals (base, joint) on x[0..35]: gradient and cost
     {
@@ -786,17 +845,32 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         qdiag[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, false) : 0.0f) + a.reg : 0.0f;
         qdiag_e[i] = mine ? (row < 36 ? wdiag(a, row < 36 ? row : 0, true) : 0.0f) + a.reg_e : 0.0f;
     }
-    // the Jacobian tiles and the gradient entries of node k + 1 are requested while node k is contracted (one node per
-    // iteration with its loads at the top waited a full memory latency per node: 6 k cycles for 1.5 k cycles of products)
-    f32x4 Jn[JT][XT], gcol_n[XT];
+    // The compact Jacobian record and the gradient entries of node k + 1 are requested while node k is contracted (one node per
+    // iteration with its loads at the top waited a full memory latency per node).  A node's record goes through the LDS: two
+    // 16 B pieces per lane in, then every lane gathers the 24 elements of its six operand tiles at precomputed indices (cj_index;
+    // structural zeros read a slot that holds zero).
+    float* const cjbuf = colU;                      // CJ_FLOATS + the zero slot; the elimination's columns are not in use yet
+    constexpr int CJ_ZERO = CJ_FLOATS;
+    static_assert(CJ_FLOATS + 4 <= 32 * LDU && CJ_FLOATS <= 2 * 64 * 4, "record buffer");
+    int jIdx[JT][XT][4];
+#pragma unroll
+    for (int t = 0; t < JT; ++t)
+#pragma unroll
+        for (int j = 0; j < XT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = cj_index(16 * t + 4 * q4 + r, 16 * j + c);
+                jIdx[t][j][r] = ci >= 0 ? ci : CJ_ZERO;
+            }
+    if (lane == 0) *reinterpret_cast<f32x4*>(cjbuf + CJ_ZERO) = zero4();
+    const bool cj_second = 4 * (lane + 64) < CJ_FLOATS;      // the record is 97 pieces: lanes 0..32 carry a second one
+    f32x4 cjA, cjB, gcol_n[XT];
     float grow_n[XT];
     auto request_node = [&](int k) {
         const float* js = ws + wl.js + (size_t)k * JS_FLOATS;
         const float* rec = recs + (size_t)k * REC;
-#pragma unroll
-        for (int t = 0; t < JT; ++t)
-#pragma unroll
-            for (int j = 0; j < XT; ++j) Jn[t][j] = load_tile(js + (t * XT + j) * IMG, lane);
+        cjA = *reinterpret_cast<const f32x4*>(js + 4 * lane);
+        cjB = *reinterpret_cast<const f32x4*>(js + (cj_second ? 4 * (lane + 64) : 0));
         // gradient of the diagonal residuals: column HX (lanes c == 10 of tile column 2) and row HX
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
@@ -811,13 +885,19 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         const bool term = (k == N);
         f32x4 J[JT][XT], gcol[XT];
         float grow[XT];
-#pragma unroll
-        for (int t = 0; t < JT; ++t)
-#pragma unroll
-            for (int j = 0; j < XT; ++j) J[t][j] = Jn[t][j];
+        *reinterpret_cast<f32x4*>(cjbuf + 4 * lane) = cjA;
+        if (cj_second) *reinterpret_cast<f32x4*>(cjbuf + 4 * (lane + 64)) = cjB;
 #pragma unroll
         for (int i = 0; i < XT; ++i) { gcol[i] = gcol_n[i]; grow[i] = grow_n[i]; }
         request_node(k < N ? k + 1 : N);
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < JT; ++t)
+#pragma unroll
+            for (int j = 0; j < XT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) J[t][j][r] = cjbuf[jIdx[t][j][r]];
+        wave_sync();      // (the next node's record is written behind these reads: the LDS serves a wave in order)
         // mixed precision (BASELINE configs[4]): the scaled Jacobian rounded to bf16 -- or split into a bf16 head and a
         // bf16 tail, J = hi + lo -- and contracted on the bf16 matrix pipe with fp32 accumulation
         // (v_mfma_f32_16x16x16_bf16: one instruction per 16 residual rows where fp32 takes four steps); the accumulator
