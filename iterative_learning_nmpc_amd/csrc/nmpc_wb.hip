@@ -6,7 +6,7 @@
 // SQP iteration, as in nmpc_solve.hip:
 //   nmpc_wb_linearize_kernel  one thread per (problem, node): foot kinematics with first and second
 //        derivatives, dynamics defect and its non-trivial Jacobian blocks, the scaled dense residual Jacobian
-//        Js = sqrt(W) [J | res] of the swing / contact / consistency rows as a tile image, gradients of the
+//        Js = sqrt(W) [J | res] of the swing / contact / consistency rows as a compact record (cj_index), gradients of the
 //        diagonal residuals, friction-pyramid values.
 //   nmpc_wb_qp_kernel  one problem per wavefront, 48x48 homogeneous stage matrices as 3x3 tiles of 16x16 fp32 in
 //        the accumulator layout of v_mfma_f32_16x16x4_f32 (nmpc_tile.hpp: X'Y on registers, no data movement):
@@ -791,7 +791,7 @@ __device__ __forceinline__ bool n_tile_nonzero(int k, int j) { return !((k == 0 
 __device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 && j == 1); }
 
 // Diagnostic build (-DNMPC_WB_STAMPS, tools/wb_stamps.py): cycle counters of the segments of a backward stage and of
-// the phases, summed per wave and left in the first Js image of the problem.  The production kernel has no stamp.
+// the phases, summed per wave and left in the first Js record of the problem.  The production kernel has no stamp.
 #ifdef NMPC_WB_STAMPS
 #define WB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_readcyclecounter(); \
                          st_acc[i] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
