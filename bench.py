@@ -255,8 +255,9 @@ class SolveSetup:
                 "flops_per_solve": flops, "bytes_per_solve": nbytes,
                 "hbm_algorithmic_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                 "binds": ("backward sweeps: instruction issue of one wave per SIMD along the serial stage recursion (154 MFMAs + the "
-                          "elimination's dependent chain per stage); forward sweeps: what memory delivers for the stage images "
-                          "(3.4 TB/s of counter traffic over the launch, see traffic_over_algorithmic: DESIGN.md 5b (18))" if self.wbm else
+                          "elimination's dependent chain per stage); forward sweeps: the stage's own dependent chain (58 broadcasts, FMA chains, "
+                          "one crossbar move) at loaded memory latency -- 3.4 TB/s of counter traffic over the launch, see "
+                          "traffic_over_algorithmic; DESIGN.md 5b (18)" if self.wbm else
                           "instruction issue of one wave per SIMD along the serial stage recursion (MFMA + VALU + LDS of a wave "
                           "do not overlap; profiles/): neither HBM nor the MFMA peak")}
 
