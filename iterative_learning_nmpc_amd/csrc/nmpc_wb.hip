@@ -10,15 +10,19 @@
 //        diagonal residuals, friction-pyramid values.
 //   nmpc_wb_qp_kernel  one problem per wavefront, 48x48 homogeneous stage matrices as 3x3 tiles of 16x16 fp32 in
 //        the accumulator layout of v_mfma_f32_16x16x4_f32 (nmpc_tile.hpp: X'Y on registers, no data movement):
-//        prologue   Q~_k = Js'Js + diag  -- the Gauss-Newton J'WJ contraction -- on the matrix pipe, per node
-//        phase R    backward sweep: P~A~ (A~ = I + N~, only N~'s non-zero tiles multiplied), P~B~, H~ux, Huu,
-//                   H~xx on MFMA tiles; LDL' of the 30x30 Huu in column layout (lane = column, v_readlane
-//                   broadcasts) applied to [H~ux | I] -> Y, W; P~+ = H~xx - Y'Y, K~ = -W'Y on MFMA tiles
-//        phase F    forward sweep: du = K~ dx~ row-per-lane, dx+ from the model's sparse structure
+//        prologue   Q~_k = Js'Js + diag  -- the Gauss-Newton J'WJ contraction -- on the matrix pipe, per node; the operand tiles
+//                   gathered from the node's compact record through the LDS
+//        phase R    backward sweep: P~A~ (A~ = I + N~), P~B~, H~ux, Huu, H~xx -- the integrator's identity blocks as lane / row
+//                   shifts, the momentum rows (registers 0, 1 of tile row 2: pos_of) as two-step MFMA products; LDL' of the
+//                   30x30 Huu in column layout (lane = column) applied to [Huu | I] -> W: 4x4 panels factorised on wave-uniform
+//                   values, rank-1 updates of the row groups below on v_mfma_f32_4x4x1 with A broadcast (ldl_panel);
+//                   Y = W H~ux, P~+ = H~xx - Y'Y, K~' = -Y'W on MFMA tiles
+//        phase F    forward sweep: du = K~ dx~ row-per-lane (gain tiles -> LDS -> rows), dx+ from the model's sparse structure
 //        phase I    interior point on the friction pyramids, lane = stage, barrier terms G'DG / G'v in closed form
 //        phase S    step, status, write-back (warm-start shift folded in as an index map)
-// Stage data that does not fit the LDS (Q~, K~ images, 9 + 6 KB per stage) streams through an HBM workspace;
-// the per-stage record, the elimination columns and the transposition buffer live in the LDS (31 KB at N = 30).
+// Stage data that does not fit the LDS (Q~, K~' images, 6 + 6 KB per stage and sweep) streams through an HBM workspace;
+// the per-stage record, the elimination columns, the transposition buffer and the gains of the last two stages live in the LDS
+// (37.8 KB at N = 30: four waves per CU).  DESIGN.md 5b has the measurements behind every choice.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -1454,10 +1458,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             wave_sync();
             WB_STAMP(4);
             // ---- LDL' of Huu in column layout applied to the identity: W = D^-1/2 L^-1
-            // lanes 0..31: column `lane` of Huu; lanes 32..63: column lane-32 of I.  One broadcast and one FMA per
-            // multiplier; the right-hand side H~ux is NOT carried through the elimination (the compiler split a second
-            // column per lane into a pass of its own and parked all 435 multipliers in spilled SGPRs for it): Y = W H~ux
-            // is formed on the matrix pipe below.
+            // lanes 0..31: column `lane` of Huu; lanes 32..63: column lane-32 of I; row i in register i & 3 of Xq[i >> 2] (ldl_panel).
+            // The right-hand side H~ux is NOT carried through the elimination (as a second column per lane the compiler split it into
+            // a pass of its own and parked all 435 multipliers in spilled SGPRs for it): Y = W H~ux is formed on the matrix pipe below.
             f32x4 Xq[LDL_GROUPS];
             {
                 const bool is_h = lane < 32;
