@@ -110,9 +110,11 @@ def test_wholebody_any_contact_pattern(dev, oracle64):
     assert rel(X, Xo) < 1e-5 and rel(U, Uo) < 1e-5, (rel(X, Xo), rel(U, Uo))
 
 
-@pytest.mark.parametrize("B,N", [(1, 30), (3, 25), (65, 30), (5, 7), (2, 64)])
+@pytest.mark.parametrize("B,N", [(1, 30), (3, 25), (65, 30), (5, 7), (2, 64), (2, 43), (2, 44), (3, 6), (2, 5)])
 def test_wholebody_odd_batches_and_horizons(dev, oracle64, B, N):
-    """ragged batches; the reference's own horizon (25 nodes, mpc_opt.py:11-13); the 64-lane limit of lane = stage"""
+    """ragged batches; the reference's own horizon (25 nodes, mpc_opt.py:11-13); the 64-lane limit of lane = stage; the horizons
+    either side of the LDS budget that keeps the gains of two (N <= 43) or one (N >= 44) backward stages on the CU, and horizons
+    no longer than that"""
     w = wl.wholebody_trot(B=B, N=N, seed=7)
     s = _solver(w, B, dev, n_ipm=6, max_sqp_iter=2)
     X, U, st, stats = _gpu_solve(s, w)
