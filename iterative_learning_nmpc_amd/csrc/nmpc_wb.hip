@@ -1002,16 +1002,22 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     int nact_l = 0;
     unsigned my_act = 0u;
     for (int k = lane; k <= N; k += 64) cost_l += recs[(size_t)k * REC + R_COST];     // (N = 64: node 64 has no lane of its own)
-    if (lane < N) {
-        const float* rec = recs + (size_t)lane * REC;
-        my_act = reinterpret_cast<const unsigned*>(rec)[R_ACT];
-        nact_l = __popc(my_act);
-        mu_l = a.mu0 * (float)nact_l;
+    float s_init[NG], l_init[NG], c_init[NG], r_init[NU];      // (the first sweep's barrier terms are formed from these, below)
+    {
+        const float* rec = recs + (size_t)(lane < N ? lane : 0) * REC;
+        if (lane < N) {
+            my_act = reinterpret_cast<const unsigned*>(rec)[R_ACT];
+            nact_l = __popc(my_act);
+            mu_l = a.mu0 * (float)nact_l;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) r_init[i] = rec[R_R + i];
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            const float s = fmaxf(-rec[R_C + j], a.s_min);
-            AT(sv, lane, j) = s;
-            AT(lv, lane, j) = a.mu0 * fast_rcp(s);
+            c_init[j] = rec[R_C + j];
+            s_init[j] = fmaxf(-c_init[j], a.s_min);
+            l_init[j] = a.mu0 * fast_rcp(s_init[j]);
+            if (lane < N) { AT(sv, lane, j) = s_init[j]; AT(lv, lane, j) = l_init[j]; }
         }
     }
     const float cost = wave_sum(cost_l);
@@ -1051,16 +1057,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             }
         }
     };
-    auto write_ipm_terms = [&](float tau) {      // the same from memory (first sweep)
-        const int kl = lane < N ? lane : 0;
-        const float* rec = recs + (size_t)kl * REC;
-        float sj[NG], lj[NG], cj[NG], rr[NU];
-#pragma unroll
-        for (int j = 0; j < NG; ++j) { sj[j] = AT(sv, kl, j); lj[j] = AT(lv, kl, j); cj[j] = rec[R_C + j]; }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) rr[i] = rec[R_R + i];
-        ipm_terms(tau, sj, lj, cj, rr);
-    };
 
     if (lane < N) ipm[lane * IPMW + IPMW - 1] = 0.0f;
     // the weight-derived constants of the backward sweep (loads from the argument block: once per kernel, unlike the index maps)
@@ -1077,6 +1073,9 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         }
 #pragma unroll
     for (int i = 0; i < 12; ++i) rs_free_w[i] = __builtin_amdgcn_rsqf((a.W[RY_FREG + i] + a.reg) + 0.0f);
+    // barrier terms of the first sweep, from the registers of the cold start (read back from memory they cost a store -> load trip)
+    ipm_terms(use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f, s_init, l_init, c_init, r_init);
+    wave_sync();
     bool qp_ok = true;
     // What a backward sweep starts from -- terminal P~ (nine tiles), the records of stages N-1 and N-2, the lower Q~ tiles of stage
     // N-1 -- is the same for every sweep of a call and is requested at the top of the interior-point phase BEFORE it, so that the
@@ -1097,7 +1096,6 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
     request_sweep();
     for (int ii = 0; ii < n_sweeps; ++ii) {
         const float tau = use_ipm ? fmaxf(a.sigma * mu_sum / (float)n_act, a.tau_min) : 0.0f;
-        if (ii == 0) { write_ipm_terms(tau); wave_sync(); }
         // Everything below that is derived from the lane index -- the index maps of the tile synthesis, LDS addresses of the layout
         // changes, masks -- is recomputed at the top of every sweep from a copy of the lane index the optimiser cannot see through:
         // ~150 integer operations per sweep.  Computed once per kernel (where loop-invariant code motion puts them) these ~100
