@@ -1484,7 +1484,13 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
 #pragma unroll
             for (int i = 0; i < XT; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)kn * QT_FLOATS + (i * XT + j) * IMG, lane);
+                for (int j = 0; j <= i; ++j) Qn[i][j] = load_tile(Qimg + (size_t)
+#ifdef WB_T_ONEQ      // timing build: every stage reads the Q~ tiles of stage 0 (cache-resident; results are wrong)
+                                                    (a.B < 0 ? kn : 0)
+#else
+                                                    kn
+#endif
+                                                    * QT_FLOATS + (i * XT + j) * IMG, lane);
             rec_pref = *reinterpret_cast<const f32x4*>(recs + (size_t)(k > 1 ? k - 2 : 0) * REC + (4 * lane < REC ? 4 * lane : 0));
             WB_STAMP(5);
             // transposed tiles: Ht[i][j] = (lower tile (i,j))', i >= j
