@@ -786,10 +786,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 // lane row q (16 lanes) of the result takes lane row q + 1 of `a`, the last lane row takes lane row 0 of `b`: the rows 4(q+1)..
 // of a tile column, continued into the next tile, moved up by one quad (ds_bpermute: the LDS crossbar, no LDS memory)
-__device__ __forceinline__ float rows_up(float a, float b, int up_addr, bool last_row) {
-    const int x = __builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(a));
-    const int y = __builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(b));
-    return __int_as_float(last_row ? y : x);
+// (one crossbar move: the lane row that nobody reads `a` from -- row 0 -- offers `b` instead)
+__device__ __forceinline__ float rows_up(float a, float b, int up_addr, bool first_row) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(up_addr, __float_as_int(first_row ? b : a)));
 }
 __device__ __forceinline__ bool n_tile_nonzero(int k, int j) { return !((k == 0 && j == 0) || (k == 1 && j == 0) || (k == 1 && j == 1)); }
 __device__ __forceinline__ bool b_tile_nonzero(int k, int j) { return !(k == 0 && j == 1); }
@@ -1176,7 +1175,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         const int up_addr = 4 * ((lane + 16) & 63);
         const int down_addr = 4 * ((lane + 48) & 63);               // the lane one lane row (16 lanes) before this one
         const float dt_qn0 = (q4 > 0) ? dt : 0.0f;
-        const bool last_row = lane >= 48;
+        const bool first_row = lane < 16;
         const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
         const float dt_q0 = (q4 == 0) ? dt : 0.0f;
         const bool hx_col = (c == HX - 32), hx_row = (q4 == HXQ);     // HX = 38: column 6 of tile column 2; row 6 of tile row 2 = lane row 1, register 2
@@ -1350,13 +1349,13 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     for (int j = 0; j < XT; ++j) {
                         Hux[0][j][0] = __builtin_fmaf(dt, PA[1][j][2], Hux[0][j][0]);
                         Hux[0][j][1] = __builtin_fmaf(dt, PA[1][j][3], Hux[0][j][1]);
-                        Hux[0][j][2] = __builtin_fmaf(dt, rows_up(PA[1][j][0], PA[2][j][0], up_addr, last_row), Hux[0][j][2]);
-                        Hux[0][j][3] = __builtin_fmaf(dt, rows_up(PA[1][j][1], PA[2][j][1], up_addr, last_row), Hux[0][j][3]);
+                        Hux[0][j][2] = __builtin_fmaf(dt, rows_up(PA[1][j][0], PA[2][j][0], up_addr, first_row), Hux[0][j][2]);
+                        Hux[0][j][3] = __builtin_fmaf(dt, rows_up(PA[1][j][1], PA[2][j][1], up_addr, first_row), Hux[0][j][3]);
                     }
                     Huu[0][0][0] = __builtin_fmaf(dt, PB[1][0][2], Huu[0][0][0]);
                     Huu[0][0][1] = __builtin_fmaf(dt, PB[1][0][3], Huu[0][0][1]);
-                    Huu[0][0][2] = __builtin_fmaf(dt, rows_up(PB[1][0][0], PB[2][0][0], up_addr, last_row), Huu[0][0][2]);
-                    Huu[0][0][3] = __builtin_fmaf(dt, rows_up(PB[1][0][1], PB[2][0][1], up_addr, last_row), Huu[0][0][3]);
+                    Huu[0][0][2] = __builtin_fmaf(dt, rows_up(PB[1][0][0], PB[2][0][0], up_addr, first_row), Huu[0][0][2]);
+                    Huu[0][0][3] = __builtin_fmaf(dt, rows_up(PB[1][0][1], PB[2][0][1], up_addr, first_row), Huu[0][0][3]);
                 }
                 if (i == 1) {
                     // kk = 2, inputs a_16, a_17: dt at (v_16, a_16), (v_17, a_17) -- rows 34, 35 of X (registers 2, 3 of lane row 0 of tile
