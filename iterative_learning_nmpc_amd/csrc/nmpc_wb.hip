@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
         const int down_addr = 4 * ((lane + 48) & 63);               // the lane one lane row (16 lanes) before this one
         const float dt_qn0 = (q4 > 0) ? dt : 0.0f;
         const bool first_row = lane < 16;
-        const int q3_addr = 4 * (48 + c), x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
+        const int x16_addr = 4 * (lane ^ 16), x32_addr = 4 * (lane ^ 32);
         const float dt_q0 = (q4 == 0) ? dt : 0.0f;
         const bool hx_col = (c == HX - 32), hx_row = (q4 == HXQ);     // HX = 38: column 6 of tile column 2; row 6 of tile row 2 = lane row 1, register 2
         // where this lane finds, in the stage record, the defects of its columns (one per tile column) ...
@@ -1398,6 +1398,14 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
             // ---- H = Q~ + P~A~ + N~'(P~A~), lower tiles only; the upper ones and the symmetrisation of the diagonal
             // tiles come back transposed from the LDS: H~xx is symmetric bit for bit
             f32x4 H[XT][XT];
+            // registers 2, 3 of tile row 0 of P~A~, one lane row back (lane row 0 reads lane row 3): rows q_2.. onto rows v_2.. of tile row 1
+            // and rows q_14, q_15 onto v_14, v_15 of tile row 2 -- one crossbar move per register serves both
+            float pa_dn2[XT], pa_dn3[XT];
+#pragma unroll
+            for (int j = 0; j < XT; ++j) {
+                pa_dn2[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][2])));
+                pa_dn3[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][3])));
+            }
 #pragma unroll
             for (int i = 0; i < XT; ++i) {
 #pragma unroll
@@ -1408,8 +1416,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                     // defects of its rows (twelve fma per column tile), the four lane rows of a column meet through the crossbar
 #pragma unroll
                     for (int j = 0; j < XT; ++j) {
-                        const float v14 = __int_as_float(__builtin_amdgcn_ds_bpermute(q3_addr, __float_as_int(PA[0][j][2])));
-                        const float v15 = __int_as_float(__builtin_amdgcn_ds_bpermute(q3_addr, __float_as_int(PA[0][j][3])));
+                        const float v14 = pa_dn2[j], v15 = pa_dn3[j];
                         H[2][j][0] = __builtin_fmaf(dt_q0, v14, H[2][j][0]);
                         H[2][j][1] = __builtin_fmaf(dt_q0, v15, H[2][j][1]);
                         H[2][j][2] = __builtin_fmaf(dt_q0, PA[1][j][0], H[2][j][2]);
@@ -1430,8 +1437,7 @@ __global__ __launch_bounds__(64, 1) void nmpc_wb_qp_kernel(const WbArgs a) {
                         // 4q+2, 4q+3 onto rows 4(q+1), 4(q+1)+1 (registers 2, 3 -> 0, 1 one lane row further on: one crossbar move each)
 #pragma unroll
                         for (int j = 0; j <= 1; ++j) {
-                            const float d2 = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][2])));
-                            const float d3 = __int_as_float(__builtin_amdgcn_ds_bpermute(down_addr, __float_as_int(PA[0][j][3])));
+                            const float d2 = pa_dn2[j], d3 = pa_dn3[j];
                             H[1][j][0] = __builtin_fmaf(dt_qn0, d2, H[1][j][0]);
                             H[1][j][1] = __builtin_fmaf(dt_qn0, d3, H[1][j][1]);
                             H[1][j][2] = __builtin_fmaf(dt, PA[0][j][0], H[1][j][2]);
